@@ -1,0 +1,184 @@
+/*
+ * mst_hip.h -- C ABI of libmst_hip.so: the MI355X (gfx950) kernels behind the Medical Slice
+ * Transformer hot path  DinoV2ClassifierSlice.forward  (+ its save_attn read-outs).
+ *
+ * The reference (gabrielfnayres/new-vit) has no FFI: the path sits behind a Python class
+ * (mst/models/dino.py:32-275).  This header is the boundary the build introduces underneath that
+ * class: plain device pointers, sizes and a hipStream_t; no torch types; no
+ * allocation inside (the caller passes a workspace); every call is asynchronous on `stream` and
+ * re-entrant for distinct streams; status codes instead of exceptions (0 = ok, message via
+ * mst_last_error()).  Each entry point cites the reference lines whose arithmetic it replaces
+ * (paths relative to the reference root).  The reference-side binding is in INTEGRATION.md.
+ *
+ * Layouts: all matrices row-major.  "compute dtype" T is MST_F16 or MST_BF16 (MFMA operands,
+ * fp32 accumulate) or MST_F32 (exact fp32 MFMA).  The residual stream, LayerNorm statistics,
+ * softmax and every bias/affine parameter are fp32 in all modes.
+ */
+#ifndef MST_HIP_H
+#define MST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mst_stream_t; /* hipStream_t */
+
+enum mst_dtype { MST_F32 = 0, MST_F16 = 1, MST_BF16 = 2 };
+
+enum mst_status {
+    MST_OK = 0,
+    MST_EINVAL = 1,     /* bad argument / unsupported shape */
+    MST_EWORKSPACE = 2, /* workspace too small */
+    MST_ELAUNCH = 3     /* HIP launch error */
+};
+
+enum mst_epilogue {
+    MST_EPI_BIAS = 0,      /* C = A W^T + b                               (any linear)            */
+    MST_EPI_BIAS_GELU = 1, /* C = gelu_erf(A W^T + b)                     mlp.py:34-36            */
+    MST_EPI_BIAS_RELU = 2, /* C = relu(A W^T + b)                         transformer_blocks.py:586 */
+    MST_EPI_RESIDUAL = 3   /* C(f32) += gamma * (A W^T + b)               block.py:90-94,112-113  */
+};
+
+enum mst_fusion_type { MST_FUSION_TRANSFORMER = 0, MST_FUSION_LINEAR = 1, MST_FUSION_AVERAGE = 2 };
+
+/* Library ---------------------------------------------------------------------------------- */
+int mst_version(void);
+const char* mst_last_error(void); /* thread-local message of the last failing call */
+
+/* Per-op entry points (unit parity; also what mst_vit_encode / mst_slice_fusion launch) ----- */
+
+/* nn.LayerNorm over the last dim: block.py:63,75; vision_transformer.py:165,263 (eps 1e-6);
+ * transformer_blocks.py:499-500, dino.py:95 (eps 1e-5).  x fp32 [rows, cols] with row stride
+ * x_stride (elements); out dtype f32/f16/bf16 with row stride out_stride.  cols even, <= 1024. */
+int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                  void* out, int out_dtype, int64_t out_stride, int64_t rows, int cols, float eps,
+                  mst_stream_t stream);
+
+/* nn.Linear / F.linear with fused epilogue: attention.py:58,67; mlp.py:35,38;
+ * transformer_blocks.py:166,283,586; dino.py:135,166.
+ * C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]).  A and W share one dtype.
+ *   16-bit A/W: MFMA 16x16x32 path; needs K % 64 == 0, N % 128 == 0, 16-byte aligned rows.
+ *   f32   A/W: exact fp32 MFMA path; needs K % 16 == 0; any M, N.
+ * c_dtype: f32 or (16-bit A only) the A dtype; MST_EPI_RESIDUAL needs c_dtype f32 (C is read and
+ * written, gamma = LayerScale vector or NULL: layer_scale.py:26-27).
+ * Columns n < scale_cols are multiplied by col_scale after the bias (q * head_dim^-0.5 of
+ * attention.py:60 folded into the QKV projection); pass scale_cols = 0 for none. */
+int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ldw, const float* bias,
+             void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
+             const float* gamma, float col_scale, int scale_cols, mst_stream_t stream);
+
+/* softmax(q k^T) v per (sequence, head), q pre-scaled: attention.py:56-66 (== xformers
+ * memory_efficient_attention, attention.py:84).  qkv [n_seq*N, 3*heads*head_dim] packed as the
+ * reference's fused projection lays it out (q | k | v, head-major inside each); out
+ * [n_seq*N, heads*head_dim].  16-bit dtypes: head_dim == 64 (flash-style, never materialises
+ * [N,N]); f32: head_dim == 64. */
+int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, void* out,
+                  mst_stream_t stream);
+
+/* Row 0 (CLS query) of the softmax, all heads: what dino.py:226-243 stores and
+ * dino.py:190-192 consumes.  probs fp32 [n_seq, heads, N]. */
+int mst_attention_cls_probs(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim,
+                            float* probs, mst_stream_t stream);
+
+/* The full softmax matrix (dino.py:232-241 `attention_maps` entry): probs fp32
+ * [n_seq, heads, N, N].  API parity for get_attention_cls (dino.py:204-212); O(N^2) memory. */
+int mst_attention_probs_full(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim,
+                             float* probs, mst_stream_t stream);
+
+/* Bicubic resampling of the patch position grid: vision_transformer.py:179-211
+ * (F.interpolate bicubic, antialias off, scale_factor=(g+0.1)/M).  pos_patch fp32 [M*M, E] ->
+ * out fp32 [gh*gw, E]. */
+int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset,
+                         float* out, mst_stream_t stream);
+
+/* Gray->RGB + Conv2d(3,E,14,14) + flatten + CLS/register rows + position add:
+ * dino.py:125-127; patch_embed.py:68-81; vision_transformer.py:213-232.
+ * vol [n, H, W] (in_dtype f32/f16/bf16), wp = channel-summed kernel [E][224] in compute dtype
+ * (k = ky*16+kx, kx 14,15 zero), prefix fp32 [1+R, E] (row 0 = cls_token + pos[0], rows 1..R =
+ * register tokens), pos_patch fp32 [Np, E].  Writes tokens x fp32 [n, 1+R+Np, E]. */
+int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const void* wp, int dtype,
+                    const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
+                    int E, float* x, mst_stream_t stream);
+
+/* Whole per-slice encoder ------------------------------------------------------------------ */
+typedef struct mst_vit_layer {
+    const float* ln1_w; const float* ln1_b;       /* block.py:63  */
+    const void* qkv_w;  const float* qkv_b;       /* attention.py:50  [3E,E] compute dtype */
+    const void* proj_w; const float* proj_b;      /* attention.py:52  [E,E] */
+    const float* ls1;                             /* layer_scale.py:25 or NULL */
+    const float* ln2_w; const float* ln2_b;       /* block.py:75  */
+    const void* fc1_w;  const float* fc1_b;       /* mlp.py:28  [4E,E] */
+    const void* fc2_w;  const float* fc2_b;       /* mlp.py:30  [E,4E] */
+    const float* ls2;
+} mst_vit_layer;
+
+typedef struct mst_vit_weights {
+    int embed_dim, depth, num_heads, num_registers;
+    int compute_dtype;            /* MST_F16 / MST_BF16 / MST_F32 */
+    int grid_h, grid_w;           /* patch grid pos_patch was prepared for */
+    const void* patch_w;          /* [E][224] compute dtype (f32 mode: f32) */
+    const float* patch_b;         /* [E] */
+    const float* prefix;          /* [1+R, E] */
+    const float* pos_patch;       /* [grid_h*grid_w, E] */
+    const mst_vit_layer* layers;  /* [depth], host memory */
+    const float* norm_w; const float* norm_b; /* vision_transformer.py:165 */
+} mst_vit_weights;
+
+/* DinoVisionTransformer.forward on n_slices gray slices (vision_transformer.py:254-270,324-329;
+ * block.py:89-114) -> normalised CLS embeddings cls_out fp32 [n_slices, E].
+ * cls_probs (nullable) fp32 [n_layers_probs, n_slices, heads, N]: CLS-row softmax of the LAST
+ * n_layers_probs blocks (1 is all the reference consumes: dino.py:190; depth reproduces the
+ * whole `attention_maps` list, CLS rows only).
+ * chunk_slices: slices processed per pass (activations of one pass stay resident in the 256 MB
+ * Infinity Cache); ws must hold mst_vit_workspace_bytes(...). */
+size_t mst_vit_workspace_bytes(const mst_vit_weights* w, int H, int W, int chunk_slices);
+int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int n_slices, int H, int W,
+                   float* cls_out, float* cls_probs, int n_layers_probs, int chunk_slices,
+                   void* ws, size_t ws_bytes, mst_stream_t stream);
+
+/* Across-slice transformer + head ---------------------------------------------------------- */
+typedef struct mst_fusion_weights {
+    int emb_in;      /* E of the encoder */
+    int emb;         /* E after the optional bottleneck (dino.py:75-78) */
+    int out_ch;      /* 0 = no head (enable_linear=False, dino.py:103) */
+    int fusion_type; /* mst_fusion_type (dino.py:144-157) */
+    int num_heads;   /* 12 (dino.py:87) */
+    const float* bottleneck_w; const float* bottleneck_b; /* [emb, emb_in] or NULL */
+    const float* slice_pos_emb;                           /* [256, emb] or NULL (dino.py:82) */
+    const float* cls_token;                               /* [emb] (dino.py:97) */
+    const float* ln1_w; const float* ln1_b;               /* transformer_blocks.py:499 */
+    const float* in_proj_w; const float* in_proj_b;       /* [3emb, emb] */
+    const float* out_proj_w; const float* out_proj_b;
+    const float* ln2_w; const float* ln2_b;
+    const float* lin1_w; const float* lin1_b;             /* dim_feedforward = emb (dino.py:88) */
+    const float* lin2_w; const float* lin2_b;
+    const float* norm_w; const float* norm_b;             /* dino.py:95 */
+    const float* rope_freqs;                              /* [head_dim/2] or NULL (RoPE) */
+    const float* head_w; const float* head_b;             /* [out_ch, emb*] (dino.py:103) */
+} mst_fusion_weights;
+
+/* dino.py:134-166 after the encoder: bottleneck, slice position embedding, CLS concat,
+ * nn.TransformerEncoder(1 layer, norm_first) + final LayerNorm (transformer_blocks.py:565-587,
+ * 29-318), row 0, linear head.  emb fp32 [B*D, emb_in]; key_padding_mask uint8 [B, D]
+ * (1 = padded slice; NULL = none) -- the CLS column is prepended inside (dino.py:147-150).
+ * features fp32 [B, F] (F = emb; emb*D for 'linear'), logits fp32 [B, out_ch] (nullable),
+ * slice_probs fp32 [B, heads, 1+D, 1+D] (nullable; transformer_blocks.py:266-295). */
+size_t mst_fusion_workspace_bytes(const mst_fusion_weights* w, int B, int D);
+int mst_slice_fusion(const mst_fusion_weights* w, const float* emb, int B, int D,
+                     const uint8_t* key_padding_mask, float* features, float* logits,
+                     float* slice_probs, void* ws, size_t ws_bytes, mst_stream_t stream);
+
+/* Saliency read-outs: dino.py:173-202.  cls_probs_last fp32 [n, heads, N] (N = 1+R+Np),
+ * slice_probs fp32 [B, sheads, 1+D, 1+D], n = B*D.  Outputs (each nullable): plane fp32
+ * [n, heads, Np], slice_attn fp32 [n], maps fp32 [n, heads, Np]. */
+int mst_attention_readout(const float* cls_probs_last, const float* slice_probs, int B, int D,
+                          int heads, int N, int num_registers, int sheads, float* plane,
+                          float* slice_attn, float* maps, mst_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_HIP_H */

@@ -1,0 +1,303 @@
+// Flash-style softmax(q k^T) v for the per-slice ViT blocks: head_dim 64, non-causal, arbitrary N
+// (257 at 224^2, 1370 at 518^2) with tail masking; 16-bit MFMA operands, fp32 scores/softmax/acc.
+// The [N,N] score matrix of attention.py:61-63 is never materialised.
+//
+// Workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys are shared through a 2-deep LDS ring,
+// register-staged (global loads for tile t+1 are issued before the MFMAs of tile t and written to
+// LDS after them: one barrier per tile).  Per wave and tile:
+//   S^T[key][q] = K . Q^T   (v_mfma_f32_32x32x16, K rows via ds_read_b128 from an XOR-swizzled
+//                            image, Q fragments resident in registers)  -> the query sits on the
+//                            lane, so the row max / sum are in-lane plus ONE cross-half shuffle;
+//   O^T[d][q]  += V^T . P^T  the S^T accumulator registers, converted to 16-bit in place, ARE the
+//                            B operand (k order 16s+8(j>>2)+4h+(j&3)); the matching V^T fragment is
+//                            fetched with ds_read_b64_tr_b16 (hardware transpose) from a row-major
+//                            V image swizzled so the 32-lane halves cover one full bank row.
+// q arrives pre-scaled by head_dim^-0.5 (folded into the QKV projection epilogue).
+//
+// Reference arithmetic: attention.py:56-66 (and dino.py:226-243 for the stored probabilities).
+#include "mst_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KV_TILE_BYTES = 64 * 128;  // 64 keys x 64 dims x 2 B
+
+template <typename T>
+__device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const char* p_hi) {
+    typedef typename V8<T>::type vec8;
+    union { struct { s16x4 lo, hi; } s; vec8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_lo));
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_hi));
+    return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                     int N, int heads) {
+    typedef typename V8<T>::type vec8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];
+    char* const Ks = smem;
+    char* const Vs = smem + 2 * KV_TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = blockIdx.x, h = blockIdx.y, seq = blockIdx.z;
+    const int E = heads * 64, ld = 3 * E;
+    const T* base = qkv + (int64_t)seq * N * ld;
+    const int h2 = lane >> 5;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): Q[q = lane&31][d = 16*ds + 8*h2 + j]
+    const int q = qb * 128 + wave * 32 + (lane & 31);
+    const bool wave_active = (qb * 128 + wave * 32) < N;
+    vec8 bq[4];
+    {
+        const int qc = q < N ? q : N - 1;
+        const T* qp = base + (int64_t)qc * ld + h * 64 + h2 * 8;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) bq[ds] = *reinterpret_cast<const vec8*>(qp + ds * 16);
+    }
+
+    // ---- K/V staging map: thread -> key row r, 16-byte chunks c0, c0+1
+    const int sr = tid >> 2, sc0 = (tid & 3) * 2;
+    const int k_off0 = sr * 128 + ((sc0 ^ ((sr >> 1) & 7)) * 16);
+    const int k_off1 = sr * 128 + (((sc0 + 1) ^ ((sr >> 1) & 7)) * 16);
+    const int v_off0 = sr * 128 + ((sc0 ^ (((sr >> 1) & 1) << 2)) * 16);
+    const int v_off1 = sr * 128 + (((sc0 + 1) ^ (((sr >> 1) & 1) << 2)) * 16);
+    u32x4 rk0, rk1, rv0, rv1;
+    auto gload = [&](int t) {
+        int key = t * 64 + sr;
+        key = key < N ? key : N - 1;
+        const T* kp = base + (int64_t)key * ld + E + h * 64 + sc0 * 8;
+        rk0 = *reinterpret_cast<const u32x4*>(kp);
+        rk1 = *reinterpret_cast<const u32x4*>(kp + 8);
+        rv0 = *reinterpret_cast<const u32x4*>(kp + E);
+        rv1 = *reinterpret_cast<const u32x4*>(kp + E + 8);
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off0) = rk0;
+        *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off1) = rk1;
+        *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off0) = rv0;
+        *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off1) = rv1;
+    };
+
+    // ---- per-lane LDS read offsets
+    // K (ds_read_b128): row = kb*32 + (lane&31), chunk = 2*ds + h2, slot = chunk ^ ((row>>1)&7)
+    const int krow = lane & 31;
+    const int ksw = (krow >> 1) & 7;  // kb*32 does not change ((row>>1)&7)
+    // V (ds_read_b64_tr_b16): 16-lane group g: rows key0 + (i>>2), key0 = ks*16 + 4*h2,
+    // columns db*32 + 16*(g&1) + 4*(i&3) .. +3  ->  chunk = db*4 + (g&1)*2 + ((i&3)>>1), +8 B if i odd
+    const int vi = lane & 15;
+    const int vrow = 4 * h2 + (vi >> 2);
+    const int vsw = ((vrow >> 1) & 1) << 2;  // ks*16 and +8 do not change ((row>>1)&1)
+    const int vchunk = ((lane >> 4) & 1) * 2 + ((vi & 3) >> 1);
+    const int v_lane_off = vrow * 128 + (vi & 1) * 8;
+
+    f32x16 oT[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[0][r] = oT[1][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (N + 63) >> 6;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        if (wave_active) {
+            const char* Kb = Ks + buf * KV_TILE_BYTES;
+            const char* Vb = Vs + buf * KV_TILE_BYTES;
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + (kb * 32 + krow) * 128 +
+                                                                  (((2 * ds + h2) ^ ksw) * 16));
+                    s[kb] = mfma32(a, bq[ds], s[kb]);
+                }
+            }
+            if (t == nt - 1 && (N & 63)) {  // mask keys >= N (wave-uniform branch)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                        if (key >= N) s[kb][r] = -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const float mc = m_new * LOG2E;
+            m_run = m_new;
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mc));
+                    s[kb][r] = p;
+                    lsum += p;
+                }
+            l_run = l_run * alpha + lsum;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    oT[0][r] *= alpha;
+                    oT[1][r] *= alpha;
+                }
+            }
+            vec8 pf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[ks][j] = (T)s[ks >> 1][(ks & 1) * 8 + j];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* p = Vb + ks * 16 * 128 + v_lane_off + (((db * 4 + vchunk) ^ vsw) * 16);
+                    const vec8 vf = tr_pair<T>(p, p + 8 * 128);
+                    oT[db] = mfma32(vf, pf[ks], oT[db]);
+                }
+            }
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (wave_active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q < N) {
+            T* op = out + ((int64_t)seq * N + q) * E + h * 64 + 4 * h2;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __attribute__((ext_vector_type(4))) T o4;
+                    o4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (T)(oT[db][g * 4 + e] * inv);
+                    *reinterpret_cast<o4*>(op + db * 32 + 8 * g) = pk;
+                }
+        }
+    }
+}
+
+// ---- CLS-row probabilities: softmax_j(q_0 . k_j) per (sequence, head) -> probs[seq][h][N] fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qkv, float* __restrict__ probs,
+                                                        int N, int heads, int hd) {
+    extern __shared__ float sm[];  // [hd] q0 | [N] scores | [8] reduce
+    float* q0 = sm;
+    float* sc = sm + hd;
+    float* red = sc + N;
+    const int h = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
+    const int E = heads * hd, ld = 3 * E;
+    const T* base = qkv + (int64_t)seq * N * ld;
+    for (int d = tid; d < hd; d += 256) q0[d] = to_f32(base[h * hd + d]);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < N; j += 256) {
+        const T* kp = base + (int64_t)j * ld + E + h * hd;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a = fmaf(q0[d], to_f32(kp[d]), a);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < N; j += 256) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    float* po = probs + ((int64_t)seq * heads + h) * N;
+    for (int j = tid; j < N; j += 256) po[j] = sc[j] * inv;
+}
+
+// ---- full probabilities (API parity for the `attention_maps` list / rollout): one wave per query.
+template <typename T>
+__global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ qkv, float* __restrict__ probs,
+                                                         int N, int heads, int hd) {
+    extern __shared__ float sm[];  // per wave: [hd] q | [N] scores
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* qv = sm + wave * (hd + N);
+    float* sc = qv + hd;
+    const int h = blockIdx.y, seq = blockIdx.z;
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= N) return;
+    const int E = heads * hd, ld = 3 * E;
+    const T* base = qkv + (int64_t)seq * N * ld;
+    for (int d = lane; d < hd; d += 64) qv[d] = to_f32(base[(int64_t)qi * ld + h * hd + d]);
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) {
+        const T* kp = base + (int64_t)j * ld + E + h * hd;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a = fmaf(qv[d], to_f32(kp[d]), a);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    float* po = probs + (((int64_t)seq * heads + h) * N + qi) * N;
+    for (int j = lane; j < N; j += 64) po[j] = sc[j] * inv;
+}
+
+}  // namespace
+
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s) {
+    MST_CHECK_ARG(n_seq > 0 && N > 0 && heads > 0, "attention: bad sizes n_seq=%d N=%d heads=%d", n_seq, N, heads);
+    MST_CHECK_ARG(n_seq <= 65535 && heads <= 65535, "attention: grid too large");
+    const dim3 grid((N + 127) / 128, heads, n_seq), block(256);
+    if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads);
+    else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads);
+    else { mst_set_error("attention16: bad dtype %d", dt); return MST_EINVAL; }
+    return mst_check_launch("attention16");
+}
+
+int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, hipStream_t s) {
+    MST_CHECK_ARG(N > 0 && N <= 12000 && hd > 0 && hd <= 256, "cls_probs: N=%d hd=%d unsupported", N, hd);
+    const dim3 grid(heads, n_seq), block(256);
+    const size_t sh = (size_t)(hd + N + 8) * sizeof(float);
+    if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd);
+    else if (dt == MST_F16) cls_probs_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd);
+    else if (dt == MST_F32) cls_probs_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd);
+    else { mst_set_error("cls_probs: bad dtype %d", dt); return MST_EINVAL; }
+    return mst_check_launch("cls_probs");
+}
+
+int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, hipStream_t s) {
+    MST_CHECK_ARG(N > 0 && N <= 3800 && hd > 0 && hd <= 256, "probs_full: N=%d hd=%d unsupported", N, hd);
+    const dim3 grid((N + 3) / 4, heads, n_seq), block(256);
+    const size_t sh = (size_t)4 * (hd + N) * sizeof(float);
+    if (dt == MST_BF16) probs_full_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd);
+    else if (dt == MST_F16) probs_full_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd);
+    else if (dt == MST_F32) probs_full_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd);
+    else { mst_set_error("probs_full: bad dtype %d", dt); return MST_EINVAL; }
+    return mst_check_launch("probs_full");
+}

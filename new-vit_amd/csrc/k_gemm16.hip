@@ -1,0 +1,193 @@
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias)  with 16-bit (bf16 / fp16) MFMA operands, fp32 accumulate.
+//
+// Both operands are K-contiguous (A row-major activations, W as nn.Linear stores it), so MFMA
+// fragments are 16-byte row segments.  Workgroup = 256 threads = 4 waves (2x2), tile 128x128x64,
+// each wave 64x64 = 4x4 v_mfma_f32_16x16x32.  Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR
+// round trip) into a 2-deep ring; the LDS image is lane-linear, so the XOR swizzle that makes the
+// ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address and again on
+// the read (cdna guide rule 21).  W plays the MFMA "A" role so that each lane ends up with 4
+// consecutive output columns of one row: epilogue accesses are 16 B (fp32) / 8 B (16-bit) per lane.
+// 1-D grid with an XCD-aware remap: tiles that share an A panel run on one XCD's L2.
+//
+// Reference arithmetic: F.linear at attention.py:58,67; mlp.py:35-38; block.py:90-94.
+#include "mst_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+template <typename T, int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, int64_t lda,
+                                                     const T* __restrict__ W, int64_t ldw,
+                                                     const float* __restrict__ bias, OutT* C,
+                                                     int64_t ldc, int M, int N, int K,
+                                                     const float* __restrict__ gamma, float col_scale,
+                                                     int scale_cols, int tiles_n, int nwg) {
+    typedef typename V8<T>::type vec8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const As = smem;                   // [2][128][64] T
+    char* const Ws = smem + 2 * TILE_BYTES;  // [2][128][64] T
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- LDS-DMA source addresses: instruction i of this wave fills tile rows rb*8 .. rb*8+7
+    const T* asrc[4];
+    const T* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);  // chunk whose swizzled home is LDS slot lane&7
+        int am = m0 + r;
+        am = am < M ? am : M - 1;
+        asrc[i] = A + (int64_t)am * lda + c * 8;
+        wsrc[i] = W + (int64_t)(n0 + r) * ldw + c * 8;
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = buf * TILE_BYTES + (wave * 4 + i) * 1024;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i]), LDS_PTR(As + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i]), LDS_PTR(Ws + off), 16, 0, 0);
+            asrc[i] += BK;
+            wsrc[i] += BK;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int sw = (lane >> 1) & 7;  // ((row >> 1) & 7) for row = 16*k + (lane & 15)
+    const int a_row_off = (wm * 64 + (lane & 15)) * 128;
+    const int w_row_off = (wn * 64 + (lane & 15)) * 128;
+
+    const int nk = K / BK;
+    stage(0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile t has landed; every wave is done reading the other buffer
+        if (t + 1 < nk) stage((t + 1) & 1);
+        const char* Ab = As + (t & 1) * TILE_BYTES;
+        const char* Wb = Ws + (t & 1) * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
+            vec8 af[4], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                af[j] = *reinterpret_cast<const vec8*>(Ab + a_row_off + j * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wf[i] = *reinterpret_cast<const vec8*>(Wb + w_row_off + i * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[i], af[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*64+i*16+(lane>>4)*4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+        float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (EPI == MST_EPI_RESIDUAL && gamma) gv = *reinterpret_cast<const float4*>(gamma + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+            if (m >= M) continue;
+            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < scale_cols) v[r] *= col_scale;
+                if (EPI == MST_EPI_BIAS_GELU) v[r] = gelu_erf(v[r]);
+                if (EPI == MST_EPI_BIAS_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            OutT* cp = C + (int64_t)m * ldc + n;
+            if constexpr (EPI == MST_EPI_RESIDUAL) {
+                float4 xv = *reinterpret_cast<const float4*>(cp);
+                xv.x += gv.x * v[0];
+                xv.y += gv.y * v[1];
+                xv.z += gv.z * v[2];
+                xv.w += gv.w * v[3];
+                *reinterpret_cast<float4*>(cp) = xv;
+            } else if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                typedef __attribute__((ext_vector_type(4))) OutT o4;
+                o4 pk;
+                pk[0] = (OutT)v[0];
+                pk[1] = (OutT)v[1];
+                pk[2] = (OutT)v[2];
+                pk[3] = (OutT)v[3];
+                *reinterpret_cast<o4*>(cp) = pk;
+            }
+        }
+    }
+}
+
+template <typename T, int EPI, typename OutT>
+int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+             int64_t ldc, int64_t M, int N, int K, const float* gamma, float col_scale, int scale_cols,
+             hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = gemm16_kernel<T, EPI, OutT>;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        attr_set = true;
+    }
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
+    const int nwg = tiles_m * tiles_n;
+    kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc,
+                                                       (int)M, N, K, gamma, col_scale, scale_cols, tiles_n, nwg);
+    return mst_check_launch("gemm16");
+}
+
+template <typename T>
+int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int cdt,
+             int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float cs, int sc,
+             hipStream_t s) {
+    const bool f32out = (cdt == MST_F32);
+    switch (epi) {
+        case MST_EPI_BIAS:
+            return f32out ? launch_t<T, MST_EPI_BIAS, float>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s)
+                          : launch_t<T, MST_EPI_BIAS, T>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+        case MST_EPI_BIAS_GELU:
+            return f32out ? launch_t<T, MST_EPI_BIAS_GELU, float>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s)
+                          : launch_t<T, MST_EPI_BIAS_GELU, T>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+        case MST_EPI_BIAS_RELU:
+            return f32out ? launch_t<T, MST_EPI_BIAS_RELU, float>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s)
+                          : launch_t<T, MST_EPI_BIAS_RELU, T>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+        case MST_EPI_RESIDUAL:
+            return launch_t<T, MST_EPI_RESIDUAL, float>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+    }
+    mst_set_error("gemm16: bad epilogue %d", epi);
+    return MST_EINVAL;
+}
+
+}  // namespace
+
+int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                  void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
+                  float col_scale, int scale_cols, hipStream_t s) {
+    MST_CHECK_ARG(K > 0 && K % BK == 0, "gemm16: K=%d must be a multiple of %d", K, BK);
+    MST_CHECK_ARG(N > 0 && N % BN == 0, "gemm16: N=%d must be a multiple of %d", N, BN);
+    MST_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, "gemm16: lda/ldw must be multiples of 8, ldc of 4");
+    MST_CHECK_ARG(M < (1ll << 31) - BM, "gemm16: M too large");
+    MST_CHECK_ARG(cdt == MST_F32 || cdt == dt, "gemm16: C dtype must be f32 or the operand dtype");
+    MST_CHECK_ARG(epi != MST_EPI_RESIDUAL || cdt == MST_F32, "gemm16: residual epilogue needs f32 C");
+    if (M <= 0) return MST_OK;
+    if (dt == MST_BF16) return dispatch<bf16_t>(A, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
+    if (dt == MST_F16) return dispatch<f16_t>(A, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
+    mst_set_error("gemm16: bad operand dtype %d", dt);
+    return MST_EINVAL;
+}

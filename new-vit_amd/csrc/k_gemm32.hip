@@ -1,0 +1,153 @@
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias) in exact fp32: v_mfma_f32_32x32x2_f32 (bit-for-bit a
+// k-ordered fmaf chain, 1/16 of the bf16 MFMA rate; gfx950 has no TF32/xf32 path).
+//
+// Used for (a) the across-slice transformer and head, whose GEMMs are tiny and latency-bound, in
+// every precision mode, and (b) the whole encoder in MST_F32 ("exact parity") mode.
+// Tile 128x128x16, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32; register-staged loads with
+// full bounds checks (any M, N; K % 16 == 0); LDS rows padded to 17 dwords so the per-lane
+// ds_read_b32 fragment reads (row = lane&31, k = lane>>5) are bank-conflict-free.
+//
+// Reference arithmetic: F.linear at transformer_blocks.py:166,283,586; dino.py:135,166 (and the
+// encoder linears in fp32 mode).
+#include "mst_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDP = 17;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A, int64_t lda,
+                                                     const float* __restrict__ W, int64_t ldw,
+                                                     const float* __restrict__ bias, float* C,
+                                                     int64_t ldc, int M, int N, int K,
+                                                     const float* __restrict__ gamma, float col_scale,
+                                                     int scale_cols, int tiles_n, int nwg) {
+    __shared__ float As[BM * LDP];
+    __shared__ float Ws[BN * LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging map: 2 float4 per operand per thread
+    const int srow0 = tid >> 2, skq = (tid & 3) * 4;  // rows srow0 and srow0 + 64
+    float4 ra[2], rw[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = srow0 + u * 64;
+            ra[u] = (m0 + row < M) ? *reinterpret_cast<const float4*>(A + (int64_t)(m0 + row) * lda + k0 + skq)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[u] = (n0 + row < N) ? *reinterpret_cast<const float4*>(W + (int64_t)(n0 + row) * ldw + k0 + skq)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float* pa = As + (srow0 + u * 64) * LDP + skq;
+            float* pw = Ws + (srow0 + u * 64) * LDP + skq;
+            pa[0] = ra[u].x; pa[1] = ra[u].y; pa[2] = ra[u].z; pa[3] = ra[u].w;
+            pw[0] = rw[u].x; pw[1] = rw[u].y; pw[2] = rw[u].z; pw[3] = rw[u].w;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    gload(0);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();  // previous tile fully consumed
+        lstore();
+        __syncthreads();
+        if (t + 1 < nk) gload((t + 1) * BK);
+        const float* ap = As + (wm * 64 + (lane & 31)) * LDP + (lane >> 5);
+        const float* wp = Ws + (wn * 64 + (lane & 31)) * LDP + (lane >> 5);
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const float a0 = ap[kp * 2], a1 = ap[32 * LDP + kp * 2];
+            const float w0 = wp[kp * 2], w1 = wp[32 * LDP + kp * 2];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, a1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, a1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D[row = n_local = (r&3)+8*(r>>2)+4*(lane>>5)][col = m_local = lane&31]
+    const bool vec_ok = (ldc % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+            if (m >= M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][g * 4 + e];
+                    if (n + e < N) {
+                        if (bias) t += bias[n + e];
+                        if (n + e < scale_cols) t *= col_scale;
+                        if (EPI == MST_EPI_BIAS_GELU) t = gelu_erf(t);
+                        if (EPI == MST_EPI_BIAS_RELU) t = fmaxf(t, 0.f);
+                        if (EPI == MST_EPI_RESIDUAL && gamma) t *= gamma[n + e];
+                    }
+                    v[e] = t;
+                }
+                float* cp = C + (int64_t)m * ldc + n;
+                if (vec_ok && n + 3 < N) {
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (EPI == MST_EPI_RESIDUAL) {
+                        const float4 xv = *reinterpret_cast<const float4*>(cp);
+                        o.x += xv.x; o.y += xv.y; o.z += xv.z; o.w += xv.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) cp[e] = (EPI == MST_EPI_RESIDUAL) ? cp[e] + v[e] : v[e];
+                }
+            }
+        }
+}
+
+template <int EPI>
+int launch_t(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
+             int64_t ldc, int64_t M, int N, int K, const float* gamma, float cs, int sc, hipStream_t s) {
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    gemm32_kernel<EPI><<<dim3(nwg), dim3(256), 0, s>>>(A, lda, W, ldw, bias, C, ldc, (int)M, N, K, gamma, cs, sc,
+                                                        tiles_n, nwg);
+    return mst_check_launch("gemm32");
+}
+
+}  // namespace
+
+int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                  float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
+                  float col_scale, int scale_cols, hipStream_t s) {
+    MST_CHECK_ARG(K > 0 && K % BK == 0, "gemm32: K=%d must be a multiple of %d", K, BK);
+    MST_CHECK_ARG(N > 0, "gemm32: N=%d", N);
+    MST_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0, "gemm32: lda/ldw must be multiples of 4");
+    MST_CHECK_ARG(M < (1ll << 31) - BM, "gemm32: M too large");
+    if (M <= 0) return MST_OK;
+    switch (epi) {
+        case MST_EPI_BIAS: return launch_t<MST_EPI_BIAS>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+        case MST_EPI_BIAS_GELU: return launch_t<MST_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+        case MST_EPI_BIAS_RELU: return launch_t<MST_EPI_BIAS_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+        case MST_EPI_RESIDUAL: return launch_t<MST_EPI_RESIDUAL>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+    }
+    mst_set_error("gemm32: bad epilogue %d", epi);
+    return MST_EINVAL;
+}

@@ -1,0 +1,89 @@
+// LayerNorm over the last dim, one 64-lane wave per row, statistics by wave shuffles (two-pass in
+// registers: mean, then variance of the centred values).  HBM-bound: reads 4*cols bytes, writes
+// 2*cols (16-bit out) or 4*cols per row.
+// Reference arithmetic: nn.LayerNorm at block.py:63,75 / vision_transformer.py:165 (eps 1e-6) and
+// transformer_blocks.py:499-500 / dino.py:95 (eps 1e-5).
+#include "mst_common.h"
+
+template <int NJ, typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t xs,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ b,
+                                                        OutT* __restrict__ out, int64_t os,
+                                                        int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * xs;
+    float2 v[NJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = j * 128 + lane * 2;
+        if (c < cols) {
+            v[j] = *reinterpret_cast<const float2*>(xr + c);
+            s += v[j].x + v[j].y;
+        } else {
+            v[j] = make_float2(0.f, 0.f);
+        }
+    }
+    const float inv_n = 1.0f / (float)cols;
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = j * 128 + lane * 2;
+        if (c < cols) {
+            const float dx = v[j].x - mean, dy = v[j].y - mean;
+            q += dx * dx + dy * dy;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+    OutT* orow = out + row * os;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = j * 128 + lane * 2;
+        if (c < cols) {
+            const float2 gg = *reinterpret_cast<const float2*>(g + c);
+            const float2 bb = *reinterpret_cast<const float2*>(b + c);
+            const float y0 = (v[j].x - mean) * rstd * gg.x + bb.x;
+            const float y1 = (v[j].y - mean) * rstd * gg.y + bb.y;
+            if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float2*>(orow + c) = make_float2(y0, y1);
+            } else {
+                typedef __attribute__((ext_vector_type(2))) OutT o2;
+                o2 pk;
+                pk[0] = (OutT)y0;
+                pk[1] = (OutT)y1;
+                *reinterpret_cast<o2*>(orow + c) = pk;
+            }
+        }
+    }
+}
+
+template <typename OutT>
+static int launch_ln_t(const float* x, int64_t xs, const float* g, const float* b, void* out, int64_t os,
+                       int64_t rows, int cols, float eps, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nj = (cols + 127) / 128;
+    OutT* o = (OutT*)out;
+    if (nj <= 1) layernorm_kernel<1, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else if (nj <= 3) layernorm_kernel<3, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else if (nj <= 6) layernorm_kernel<6, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else layernorm_kernel<8, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    return mst_check_launch("layernorm");
+}
+
+int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
+                     int64_t os, int64_t rows, int cols, float eps, hipStream_t s) {
+    MST_CHECK_ARG(cols > 0 && cols <= 1024 && (cols % 2) == 0, "layernorm: cols=%d must be even and <= 1024", cols);
+    MST_CHECK_ARG((xs % 2) == 0 && (os % 2) == 0, "layernorm: row strides must be even");
+    if (rows <= 0) return MST_OK;
+    switch (odt) {
+        case MST_F32: return launch_ln_t<float>(x, xs, g, b, out, os, rows, cols, eps, s);
+        case MST_F16: return launch_ln_t<f16_t>(x, xs, g, b, out, os, rows, cols, eps, s);
+        case MST_BF16: return launch_ln_t<bf16_t>(x, xs, g, b, out, os, rows, cols, eps, s);
+    }
+    mst_set_error("layernorm: bad out dtype %d", odt);
+    return MST_EINVAL;
+}

@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libmst_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mst_hip.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MST_WAVE 64
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <typename T> struct V8;
+template <> struct V8<bf16_t> { typedef bf16x8 type; typedef bf16x4 half_type; };
+template <> struct V8<f16_t> { typedef f16x8 type; typedef f16x4 half_type; };
+
+// D(16x16 f32) += A(16x32) * B(32x16); lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+// D[row=(l>>4)*4+r][col=l&15].
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// D(32x32 f32) += A(32x16) * B(16x32); lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31];
+// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {  // nn.GELU() exact form (mlp.py:22)
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
+// so give each XCD a contiguous run of tile ids (neighbouring tiles share operand panels in its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// host side ---------------------------------------------------------------------------------
+void mst_set_error(const char* fmt, ...);
+#define MST_CHECK_ARG(cond, ...)                \
+    do {                                        \
+        if (!(cond)) {                          \
+            mst_set_error(__VA_ARGS__);         \
+            return MST_EINVAL;                  \
+        }                                       \
+    } while (0)
+int mst_check_launch(const char* what);
+
+// kernel launchers shared between translation units (all asynchronous on `s`)
+int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
+                     int64_t os, int64_t rows, int cols, float eps, hipStream_t s);
+int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                  void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
+                  float col_scale, int scale_cols, hipStream_t s);
+int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                  float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
+                  float col_scale, int scale_cols, hipStream_t s);
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s);
+int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
+int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,
+                     hipStream_t s);
+int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,
+                      hipStream_t s);
+int launch_patch_embed(const void* vol, int idt, int n, int H, int W, const void* wp, int dt,
+                       const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
+                       int E, float* x, hipStream_t s);
+int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double offset, float* out,
+                      hipStream_t s);
+int launch_slice_tokens(const float* emb, const float* cls, const float* pos, int B, int D, int E,
+                        float* xs, hipStream_t s);
+int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const uint8_t* mask,
+                      const float* rope, float* out, float* probs, hipStream_t s);
+int launch_rows_copy(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int rows,
+                     int cols, hipStream_t s);
+int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
+int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,
+                   int R, int sheads, float* plane, float* slice_attn, float* maps, hipStream_t s);

@@ -1,0 +1,262 @@
+"""CPU oracle for the MST-DINOv2 hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A functional fp32 (or fp64) PyTorch-CPU restatement of ``DinoV2ClassifierSlice.forward`` and its
+attention read-outs, written over a plain ``state_dict``.  Only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import this file; the product package
+(``new-vit_amd/mst``) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  ``tools/gen_golden.py`` ran the reference's own modules (imported from
+/root/reference in the build container) on the synthetic weights of ``mst.synth`` and wrote the
+fixtures in ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function below against
+them (the reference's own tests hold no numerical vectors: SURVEY.md section 4).
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+VIT_CFG = {  # mst/models/extern/dinov2/vision_transformer.py:340-365
+    "s": dict(embed_dim=384, depth=12, num_heads=6),
+    "b": dict(embed_dim=768, depth=12, num_heads=12),
+}
+SLICE_HEADS = 12  # mst/models/dino.py:87
+PATCH = 14        # mst/models/dino.py:66
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+def _block_prefix(sd: SD, i: int) -> str:
+    """Both key layouts: chunked ``blocks.0.i`` (vision_transformer.py:153-160) and hub ``blocks.i``."""
+    p = f"encoder.blocks.0.{i}"
+    return p if (p + ".norm1.weight") in sd else f"encoder.blocks.{i}"
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    """nn.LayerNorm over the last dim (block.py:63,75; vision_transformer.py:95,165)."""
+    mu = x.mean(-1, keepdim=True)
+    var = (x - mu).pow(2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """nn.GELU() default = exact erf form (mlp.py:22,30)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+# --------------------------------------------------------------------------------------------
+# per-slice encoder (DinoVisionTransformer)
+# --------------------------------------------------------------------------------------------
+def patch_embed(slices: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """Gray->RGB repeat (dino.py:125-127) + Conv2d(3,E,14,14) + flatten/transpose
+    (patch_embed.py:65,68-81) as one GEMM.  ``slices`` is [n,H,W]; returns [n,Np,E]."""
+    n, H, W = slices.shape
+    assert H % PATCH == 0, f"Input image height {H} is not a multiple of patch height {PATCH}"
+    assert W % PATCH == 0, f"Input image width {W} is not a multiple of patch width: {PATCH}"
+    gh, gw = H // PATCH, W // PATCH
+    cols = slices.reshape(n, gh, PATCH, gw, PATCH).permute(0, 1, 3, 2, 4).reshape(n, gh * gw, PATCH * PATCH)
+    # the three input channels are identical copies, so summing products over c equals the conv
+    wmat = w.reshape(w.shape[0], 3, PATCH * PATCH)
+    out = cols @ wmat[:, 0].t() + cols @ wmat[:, 1].t() + cols @ wmat[:, 2].t()
+    return out + b
+
+
+def interpolate_pos_encoding(pos_embed: Tensor, npatch: int, w: int, h: int,
+                             offset: float = 0.1) -> Tensor:
+    """vision_transformer.py:179-211 (bicubic, antialias off, scale_factor=(g+0.1)/M).
+    Note the reference passes (w, h) = (x.shape[2], x.shape[3]) = (H, W): l.214,220."""
+    N = pos_embed.shape[1] - 1
+    if npatch == N and w == h:
+        return pos_embed
+    pe = pos_embed.float()
+    cls_pe, patch_pe = pe[:, 0], pe[:, 1:]
+    dim = pe.shape[-1]
+    w0, h0 = w // PATCH, h // PATCH
+    M = int(math.sqrt(N))
+    assert N == M * M
+    sx, sy = float(w0 + offset) / M, float(h0 + offset) / M
+    grid = F.interpolate(patch_pe.reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
+                         antialias=False, scale_factor=(sx, sy))
+    assert (w0, h0) == tuple(grid.shape[-2:])
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((cls_pe.unsqueeze(0), grid), dim=1).to(pos_embed.dtype)
+
+
+def prepare_tokens(sd: SD, slices: Tensor) -> Tensor:
+    """vision_transformer.py:213-232 (no masks): patch-embed, CLS, +pos, registers after CLS."""
+    n, H, W = slices.shape
+    x = patch_embed(slices, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"])
+    x = torch.cat((sd["encoder.cls_token"].expand(n, -1, -1), x), dim=1)
+    x = x + interpolate_pos_encoding(sd["encoder.pos_embed"], x.shape[1] - 1, H, W)
+    reg = sd.get("encoder.register_tokens")
+    if reg is not None:
+        x = torch.cat((x[:, :1], reg.expand(n, -1, -1), x[:, 1:]), dim=1)
+    return x
+
+
+def vit_attention(x: Tensor, sd: SD, p: str, heads: int) -> Tuple[Tensor, Tensor]:
+    """attention.py:56-69 (== dino.py:226-243 with the softmax kept).  Returns (out, probs)."""
+    n, N, C = x.shape
+    d = C // heads
+    qkv = F.linear(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+    qkv = qkv.reshape(n, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
+    probs = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    out = (probs @ v).transpose(1, 2).reshape(n, N, C)
+    return F.linear(out, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), probs
+
+
+def vit_block(x: Tensor, sd: SD, p: str, heads: int) -> Tuple[Tensor, Tensor]:
+    """block.py:89-114 eval branch: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)); LN eps 1e-6."""
+    a, probs = vit_attention(layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6), sd, p, heads)
+    if (p + ".ls1.gamma") in sd:  # layer_scale.py:26-27
+        a = a * sd[p + ".ls1.gamma"]
+    x = x + a
+    h = layer_norm(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
+    h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])      # mlp.py:34-40
+    h = F.linear(gelu_erf(h), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    if (p + ".ls2.gamma") in sd:
+        h = h * sd[p + ".ls2.gamma"]
+    return x + h, probs
+
+
+def vit_encode(sd: SD, slices: Tensor, model_size: str = "s", keep: str = "none"):
+    """DinoVisionTransformer.forward (vision_transformer.py:254-270,324-329) -> normalised CLS [n,E].
+
+    keep: 'none' | 'cls' (CLS row of every block's softmax, [n,h,1,N] each) | 'full' ([n,h,N,N])."""
+    cfg = VIT_CFG[model_size]
+    x = prepare_tokens(sd, slices)
+    maps: List[Tensor] = []
+    for i in range(cfg["depth"]):
+        x, probs = vit_block(x, sd, _block_prefix(sd, i), cfg["num_heads"])
+        if keep == "cls":
+            maps.append(probs[:, :, :1].clone())
+        elif keep == "full":
+            maps.append(probs)
+    x = layer_norm(x, sd["encoder.norm.weight"], sd["encoder.norm.bias"], 1e-6)
+    return x[:, 0], maps
+
+
+# --------------------------------------------------------------------------------------------
+# across-slice transformer
+# --------------------------------------------------------------------------------------------
+def rope_rotate(t: Tensor, freqs_param: Tensor) -> Tensor:
+    """RotaryEmbedding.rotate_queries_or_keys on [B,h,L,hd] (rotary_embedding_torch.py:159-173,
+    45-62, 273-302): positions 0..L-1, interleaved pairs (x0,x1)->(-x1,x0)."""
+    L = t.shape[-2]
+    ang = torch.arange(L, dtype=t.dtype)[:, None] * freqs_param.to(t.dtype)[None, :]
+    ang = ang.repeat_interleave(2, dim=-1)                       # [L, hd]
+    tp = t.reshape(*t.shape[:-1], -1, 2)
+    rot = torch.stack((-tp[..., 1], tp[..., 0]), dim=-1).reshape(t.shape)
+    return t * ang.cos() + rot * ang.sin()
+
+
+def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
+                 rotary: Optional[str] = None) -> Tuple[Tensor, Tensor]:
+    """nn.TransformerEncoder(1 x TransformerEncoderLayer(norm_first), norm=LayerNorm)
+    (dino.py:84-96; transformer_blocks.py:565-587,29-318).  x = [B,L,E] with CLS at 0;
+    key_padding_mask bool [B,L], True = ignore.  Returns (y [B,L,E], probs [B,12,L,L])."""
+    p = "slice_fusion.layers.0"
+    B, L, E = x.shape
+    h, hd = SLICE_HEADS, E // SLICE_HEADS
+    y = layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+    qkv = F.linear(y, sd[p + ".self_attn.in_proj_weight"], sd[p + ".self_attn.in_proj_bias"])
+    q, k, v = (t.reshape(B, L, h, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))  # [B,h,L,hd]
+    if rotary == "RoPE":                                                             # l.262-264
+        fr = sd[p + ".self_attn.rotary_positional_encoding.freqs"]
+        q, k = rope_rotate(q, fr), rope_rotate(k, fr)
+    elif rotary is not None:
+        raise NotImplementedError(rotary)
+    s = (q * math.sqrt(1.0 / hd)) @ k.transpose(-2, -1)                              # l.268-275
+    if key_padding_mask is not None:                                                 # l.244-252
+        s = s + torch.zeros(B, 1, 1, L, dtype=s.dtype).masked_fill_(key_padding_mask[:, None, None, :], float("-inf"))
+    probs = s.softmax(dim=-1)
+    a = (probs @ v).transpose(1, 2).reshape(B, L, E)
+    a = F.linear(a, sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
+    x = x + a
+    f = layer_norm(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+    f = F.linear(torch.relu(F.linear(f, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])                # l.585-587, relu l.484
+    x = x + f
+    return layer_norm(x, sd["slice_fusion.norm.weight"], sd["slice_fusion.norm.bias"], 1e-5), probs
+
+
+# --------------------------------------------------------------------------------------------
+# whole model
+# --------------------------------------------------------------------------------------------
+def forward(sd: SD, source: Tensor, *, model_size: str = "s", slice_fusion_type: str = "transformer",
+            src_key_padding_mask: Optional[Tensor] = None, rotary: Optional[str] = None,
+            without_linear: bool = False, keep: str = "none") -> Dict[str, Tensor]:
+    """DinoV2ClassifierSlice.forward (dino.py:110-167).  source = [B,1,D,H,W].
+
+    Returns dict(logits|features, emb [B*D,E], vit_maps list, slice_map [B,12,L,L] or None)."""
+    B, C, D, H, W = source.shape
+    emb, maps = vit_encode(sd, source.reshape(B * C * D, H, W), model_size, keep)   # l.125-131
+    x = emb
+    if "bottleneck.weight" in sd:                                                    # l.134-135
+        x = F.linear(x, sd["bottleneck.weight"], sd["bottleneck.bias"])
+    x = x.reshape(B, D * C, -1)                                                      # l.138
+    if "slice_pos_emb.weight" in sd:                                                 # l.140-142
+        x = x + sd["slice_pos_emb.weight"][: x.shape[1]]
+    slice_map = None
+    if slice_fusion_type == "transformer":                                           # l.144-153
+        x = torch.cat([sd["cls_token"].repeat(B, 1, 1), x], dim=1)
+        m = None
+        if src_key_padding_mask is not None:
+            m = torch.cat([torch.zeros(B, 1, dtype=torch.bool), src_key_padding_mask.bool()], dim=1)
+        x, slice_map = slice_fusion(sd, x, m, rotary)
+        x = x[:, 0]
+    elif slice_fusion_type == "linear":
+        x = x.reshape(B, -1)
+    elif slice_fusion_type == "average":
+        x = x.mean(dim=1)
+    out = {"emb": emb, "vit_maps": maps, "slice_map": slice_map, "features": x}
+    if not without_linear and "linear.weight" in sd:                                 # l.164-166
+        out["logits"] = F.linear(x, sd["linear.weight"], sd["linear.bias"])
+    return out
+
+
+def plane_attention(last_vit_map: Tensor, num_registers: int = 0) -> Tensor:
+    """get_plane_attention (dino.py:189-195): CLS row of the last block, patch columns, first patch
+    zeroed, renormalised.  Accepts [n,h,N,N] or the CLS-only [n,h,1,N]."""
+    a = last_vit_map[:, :, 0, 1 + (4 if num_registers else 0):].clone()
+    a[:, :, 0] = 0
+    return a / a.sum(dim=-1, keepdim=True)
+
+
+def slice_attention(slice_map: Tensor) -> Tensor:
+    """get_slice_attention (dino.py:173-187): CLS row, slices only, renormalised, head-mean -> [B*D,1,1]."""
+    a = slice_map[:, :, 0, 1:].clone()
+    a = a / a.sum(dim=-1, keepdim=True)
+    return a.mean(dim=1).reshape(-1)[:, None, None]
+
+
+def attention_maps(last_vit_map: Tensor, slice_map: Tensor, num_registers: int = 0) -> Tensor:
+    """get_attention_maps (dino.py:197-202)."""
+    return slice_attention(slice_map) * plane_attention(last_vit_map, num_registers)
+
+
+def attention_rollout(vit_maps_full: List[Tensor]) -> Tensor:
+    """get_attention_cls (dino.py:204-212): A_0 @ A_1 @ ... @ A_last on full [n,h,N,N] maps."""
+    acc = vit_maps_full[-1]
+    for a in reversed(vit_maps_full[:-1]):
+        acc = torch.matmul(a, acc)
+    return acc
+
+
+def flops_per_volume(D: int, H: int, W: int, E: int = 384, depth: int = 12) -> float:
+    """Algorithmic FLOPs of one forward: 2 FLOP per MAC, softmax/LN/GELU not counted."""
+    Np = (H // PATCH) * (W // PATCH)
+    N = Np + 1
+    f_slice = 2.0 * Np * E * 588 + depth * (24.0 * N * E * E + 4.0 * N * N * E)
+    L = D + 1
+    f_fusion = 2.0 * L * 3 * E * E + 4.0 * L * L * E + 2.0 * L * E * E + 4.0 * L * E * E + 4.0 * E
+    return D * f_slice + f_fusion

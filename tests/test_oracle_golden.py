@@ -1,0 +1,132 @@
+"""Pins oracle/mst_oracle.py to the fixtures the REFERENCE produced (tools/gen_golden.py).
+
+CPU only.  Tolerances: the reference's own run-to-run / thread-count noise floor is 2.4e-7
+(SURVEY.md 8c), so 2e-5 absolute on O(1) quantities and 1e-4 relative on attention maps."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_l2
+from mst import synth
+from oracle import mst_oracle as O
+
+CASES = {  # name -> synth/forward kwargs  (must mirror tools/gen_golden.py)
+    "c1_1x16x224": dict(),
+    "b2_mask": dict(),
+    "bottleneck_pos": dict(use_bottleneck=True, use_slice_pos_emb=True),
+    "rope": dict(rotary="RoPE"),
+    "average": dict(slice_fusion="average"),
+    "linear32": dict(slice_fusion="linear"),
+    "size_b": dict(model_size="b"),
+}
+
+
+def test_weight_generator_pinned():
+    ref = json.loads((GOLDEN / "weights.json").read_text())
+    assert synth.state_dict_digest(synth.synth_state_dict("s", 0)) == ref["s_seed0"]
+    assert synth.state_dict_digest(synth.synth_state_dict("s", 1, img_size=518, layerscale=True, chunked=False)) == ref["s_seed1_hub518"]
+    assert float(synth.synth_volume((1, 1, 2, 28, 28), 3).double().sum()) == ref["volume_1x1x2x28x28_seed3"]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_end_to_end_matches_reference(name):
+    g = load_golden(name)
+    kw = dict(CASES[name])
+    size = kw.pop("model_size", "s")
+    fusion = kw.get("slice_fusion", "transformer")
+    sd = synth.synth_state_dict(size, int(g["seed"]), **kw)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"]) if "src_key_padding_mask" in g else None
+    with torch.no_grad():
+        out = O.forward(sd, src, model_size=size, slice_fusion_type=fusion, src_key_padding_mask=mask,
+                        rotary=kw.get("rotary"), keep="cls")
+    assert np.abs(out["emb"].numpy() - g["emb"]).max() < 2e-5
+    assert np.abs(out["features"].numpy() - g["features"]).max() < 2e-5
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() < 2e-5
+    if fusion == "transformer":
+        rows = torch.stack([m[:, :, 0] for m in out["vit_maps"]]).numpy()
+        assert np.abs(rows - g["vit_cls_rows"]).max() < 2e-5 and rel_l2(rows, g["vit_cls_rows"]) < 1e-4
+        assert np.abs(out["slice_map"].numpy() - g["slice_map"]).max() < 2e-5
+        nreg = 0
+        assert rel_l2(O.plane_attention(out["vit_maps"][-1], nreg), g["plane_attention"]) < 1e-4
+        assert rel_l2(O.slice_attention(out["slice_map"]), g["slice_attention"]) < 1e-4
+        assert rel_l2(O.attention_maps(out["vit_maps"][-1], out["slice_map"], nreg), g["attention_maps"]) < 1e-4
+
+
+def _big(name):
+    p = GOLDEN / f"{name}.npz"
+    if not p.exists():
+        pytest.skip(f"{p.name} not generated")
+    return load_golden(name)
+
+
+@pytest.mark.parametrize("name,seed_slices", [("s504_1x4x504", None)])
+def test_large_grid_matches_reference(name, seed_slices):
+    """504x504 (36x36 grid, interpolated pos-embed), 4 slices: cheap enough for the CPU suite."""
+    g = _big(name)
+    sd = synth.synth_state_dict("s", int(g["seed"]))
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    with torch.no_grad():
+        out = O.forward(sd, src, keep="cls")
+    assert np.abs(out["emb"].numpy() - g["emb"]).max() < 5e-5
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() < 5e-5
+    sub = g["plane_subset"].tolist()
+    assert rel_l2(O.plane_attention(out["vit_maps"][-1])[sub], g["plane_attention"]) < 1e-4
+    assert rel_l2(O.slice_attention(out["slice_map"]), g["slice_attention"]) < 1e-4
+
+
+def test_ops_small_vit_and_pos_interpolation():
+    g = load_golden("ops")
+    sd = {"encoder." + k[len("vit_sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vit_sd.")}
+    O.VIT_CFG["_tiny"] = dict(embed_dim=64, depth=2, num_heads=2)
+    try:
+        for tag in ("56", "84x70", "70x84"):
+            x = torch.from_numpy(g[f"vit_in_{tag}"])
+            with torch.no_grad():
+                y, _ = O.vit_encode(sd, x, "_tiny")
+            assert np.abs(y.numpy() - g[f"vit_out_{tag}"]).max() < 5e-5, tag
+    finally:
+        del O.VIT_CFG["_tiny"]
+    pe = torch.from_numpy(synth.hash_normal((1, 257, 384), 9, 1)) * 0.2
+    for tag, hw in (("518", (518, 518)), ("504", (504, 504)), ("518x224", (518, 224))):
+        n = (hw[0] // 14) * (hw[1] // 14)
+        got = O.interpolate_pos_encoding(pe, n, hw[0], hw[1])
+        assert np.abs(got.numpy() - g[f"pos224_to_{tag}"]).max() < 1e-6, tag
+
+
+@pytest.mark.parametrize("tag", ["plain", "rope"])
+def test_ops_slice_transformer_layer(tag):
+    g = load_golden("ops")
+    pre = f"tel_{tag}_sd."
+    sd = {}
+    for k, v in g.items():
+        if k.startswith(pre):
+            kk = k[len(pre):]
+            sd[("slice_fusion." + kk)] = torch.from_numpy(v)
+    x = torch.from_numpy(g[f"tel_{tag}_in"])
+    mask = torch.from_numpy(g[f"tel_{tag}_mask"])
+    rot = "RoPE" if tag == "rope" else None
+    old = O.SLICE_HEADS
+    try:
+        with torch.no_grad():
+            y, w = O.slice_fusion(sd, x, None, rot)
+            ym, wm = O.slice_fusion(sd, x, mask, rot)
+    finally:
+        O.SLICE_HEADS = old
+    assert np.abs(y.numpy() - g[f"tel_{tag}_out"]).max() < 1e-5
+    assert np.abs(ym.numpy() - g[f"tel_{tag}_out_masked"]).max() < 1e-5
+    assert np.abs(w.numpy() - g[f"tel_{tag}_weights"]).max() < 1e-6
+    assert np.abs(wm.numpy() - g[f"tel_{tag}_weights_masked"]).max() < 1e-6
+
+
+def test_error_fixture_messages():
+    ref = json.loads((GOLDEN / "errors.json").read_text())
+    sd = synth.synth_state_dict("s", 0)
+    with pytest.raises(AssertionError) as e:
+        O.vit_encode(sd, torch.zeros(2, 512, 512))
+    assert str(e.value) == ref["512x512"]["message"]
+    with pytest.raises(AssertionError) as e:
+        O.vit_encode(sd, torch.zeros(2, 224, 230))
+    assert str(e.value) == ref["224x230"]["message"]

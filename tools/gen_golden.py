@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+Run:  python tools/gen_golden.py [--only NAME ...]
+
+The reference (/root/reference, read-only) is imported in place with the loader recipe of
+SURVEY.md section 8c: synthetic parent packages whose ``__path__`` points at the reference
+directories (so its ``__init__`` files, which pull in absent optional deps, never run) and two
+minimal stand-in modules for the absent ``pytorch_lightning`` / ``torchmetrics`` bases, which carry
+no arithmetic.  Weights and inputs come from ``mst.synth`` (build-owned hash PRNG), so the GPU box
+can regenerate them bit-exactly without the reference.  Only inputs' seeds/shapes and the
+reference's OUTPUTS are stored; no reference source is copied.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT / "new-vit_amd"))
+GOLD = ROOT / "tests" / "golden"
+
+
+def load_reference():
+    import mst as build_mst  # the build's package: we need mst.synth before shadowing
+    from mst import synth
+    for k in [k for k in sys.modules if k == "mst" or k.startswith("mst.")]:
+        del sys.modules[k]
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [str(path)]
+        sys.modules[name] = m
+
+    pkg("refmst", REF / "mst")
+    pkg("refmst.models", REF / "mst/models")
+    pkg("refmst.models.utils", REF / "mst/models/utils")
+    pkg("refmst.models.extern", REF / "mst/models/extern")
+    pkg("refmst.models.extern.dinov2", REF / "mst/models/extern/dinov2")
+
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    pl.LightningModule = LightningModule
+    pl.LightningDataModule = object
+    sys.modules["pytorch_lightning"] = pl
+    tm = types.ModuleType("torchmetrics")
+
+    class _Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def update(self, *a, **k):
+            pass
+
+        def compute(self):
+            return torch.tensor(0.0)
+
+        def reset(self):
+            pass
+
+    tm.AUROC = tm.Accuracy = tm.MeanSquaredError = _Metric
+    sys.modules["torchmetrics"] = tm
+    dino = importlib.import_module("refmst.models.dino")
+    return dino, synth
+
+
+def np_(t):
+    return t.detach().cpu().float().clone().numpy()
+
+
+def build(dino, synth, seed, **kw):
+    """Reference model (pretrained=False) filled with synthetic weights."""
+    rot = kw.pop("rotary", None)
+    model = dino.DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False,
+                                       rotary_positional_encoding=rot, **kw)
+    sd = synth.synth_state_dict(kw.get("model_size", "s"), seed,
+                                use_bottleneck=kw.get("use_bottleneck", False),
+                                use_slice_pos_emb=kw.get("use_slice_pos_emb", False),
+                                slice_fusion=kw.get("slice_fusion", "transformer"), rotary=rot)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("auc_roc" in m or "acc." in m) for m in missing), missing
+    return model.eval(), sd
+
+
+@torch.no_grad()
+def case_end2end(dino, synth, name, shape, seed, *, mask=None, plane_subset=None, chunk=None, **kw):
+    model, sd = build(dino, synth, seed, **kw)
+    src = synth.synth_volume(shape, seed + 100)
+    B, _, D, H, W = shape
+    out = {"seed": seed, "shape": np.array(shape)}
+    m = None
+    if mask is not None:
+        m = torch.zeros(B, D, dtype=torch.bool)
+        for b, cnt in enumerate(mask):
+            if cnt:
+                m[b, D - cnt:] = True
+        out["src_key_padding_mask"] = m.numpy()
+    fusion = kw.get("slice_fusion", "transformer")
+    if chunk is None:
+        logits = model(src, src_key_padding_mask=m)
+        out["logits"] = np_(logits)
+        out["features"] = np_(model(src, src_key_padding_mask=m, without_linear=True))
+        emb = model.encoder(src.reshape(B * D, 1, H, W).repeat(1, 3, 1, 1))
+        out["emb"] = np_(emb)
+        if fusion == "transformer":
+            logits2 = model(src, save_attn=True, src_key_padding_mask=m)
+            assert torch.allclose(logits, logits2, atol=1e-5)
+            out["vit_cls_rows"] = np.stack([np_(a[:, :, 0]) for a in model.attention_maps])  # [12,n,h,N]
+            out["slice_map"] = np_(model.attention_maps_slice[-1])
+            out["plane_attention"] = np_(model.get_plane_attention())
+            out["slice_attention"] = np_(model.get_slice_attention())
+            # getters normalise in place: call on a fresh forward for the product (dino.py:197-202)
+            model(src, save_attn=True, src_key_padding_mask=m)
+            out["attention_maps"] = np_(model.get_attention_maps())
+    else:
+        # big shapes: encoder per chunk of slices with the reference's own hooks, then the reference
+        # slice transformer on the concatenated embeddings (identical maths: slices are independent)
+        x = src.reshape(B * D, H, W)
+        embs, cls_rows = [], []
+        for s0 in range(0, B * D, chunk):
+            model.attention_maps, model.attention_maps_slice, model.hooks = [], [], []
+            model.register_hooks()
+            e = model.encoder(x[s0:s0 + chunk, None].repeat(1, 3, 1, 1))
+            model.deregister_hooks()
+            embs.append(e)
+            cls_rows.append(model.attention_maps[-1][:, :, 0].clone())
+            model.attention_maps = []
+        emb = torch.cat(embs)
+        last = torch.cat(cls_rows)                                  # [n,h,N]
+        out["emb"] = np_(emb)
+        xs = torch.cat([model.cls_token.repeat(B, 1, 1), emb.reshape(B, D, -1)], dim=1)
+        model.attention_maps_slice, model.hooks = [], []
+        fast = torch.backends.mha.get_fastpath_enabled()
+        torch.backends.mha.set_fastpath_enabled(False)
+        model.register_hooks()
+        y = model.slice_fusion(xs)[:, 0]
+        model.deregister_hooks()
+        torch.backends.mha.set_fastpath_enabled(fast)
+        out["features"] = np_(y)
+        out["logits"] = np_(model.linear(y))
+        out["slice_map"] = np_(model.attention_maps_slice[-1])
+        model.attention_maps = [last[:, :, None, :]]
+        plane = model.get_plane_attention()
+        sl = model.get_slice_attention()
+        out["slice_attention"] = np_(sl)
+        sub = plane_subset or list(range(B * D))
+        out["plane_subset"] = np.array(sub)
+        out["plane_attention"] = np_(plane[sub])
+        out["attention_maps"] = np_((sl * plane)[sub])
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+@torch.no_grad()
+def case_ops(dino, synth):
+    """Per-op known answers at tiny dims from the reference classes themselves."""
+    vt = importlib.import_module("refmst.models.extern.dinov2.vision_transformer")
+    layers = importlib.import_module("refmst.models.extern.dinov2.layers")
+    tb = importlib.import_module("refmst.models.utils.transformer_blocks")
+    out = {}
+    # small ViT: E=64, depth 2, 2 heads, img 56 (4x4 grid), plus interpolated pos-embed at 84x70
+    vit = vt.DinoVisionTransformer(img_size=56, patch_size=14, embed_dim=64, depth=2, num_heads=2,
+                                   block_fn=lambda **k: layers.NestedTensorBlock(attn_class=layers.MemEffAttention, **k))
+    sd = {}
+    for i, (k, v) in enumerate(vit.state_dict().items()):
+        sd[k] = torch.from_numpy(synth.hash_normal(tuple(v.shape), 7, 1000 + i)) * (0.3 if v.dim() > 1 else 0.2)
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k == "norm.weight":
+            sd[k] = sd[k] + 1.0
+    vit.load_state_dict(sd)
+    vit.eval()
+    for k, v in sd.items():
+        out["vit_sd." + k] = np_(v)
+    for tag, hw in (("56", (56, 56)), ("84x70", (84, 70)), ("70x84", (70, 84))):
+        x = torch.from_numpy(synth.hash_normal((3, hw[0], hw[1]), 8, 5))
+        out[f"vit_in_{tag}"] = np_(x)
+        out[f"vit_out_{tag}"] = np_(vit(x[:, None].repeat(1, 3, 1, 1)))
+        out[f"vit_pos_{tag}"] = np_(vit.interpolate_pos_encoding(torch.zeros(1, (hw[0] // 14) * (hw[1] // 14) + 1, 64), hw[0], hw[1]))
+    # pos-embed interpolation of the real geometry: 16x16 grid (224) -> 37x37, 36x36, 37x16
+    vs = vt.vit_small(patch_size=14)
+    pe = torch.from_numpy(synth.hash_normal((1, 257, 384), 9, 1)) * 0.2
+    vs.pos_embed.data.copy_(pe)
+    for tag, hw in (("518", (518, 518)), ("504", (504, 504)), ("518x224", (518, 224))):
+        n = (hw[0] // 14) * (hw[1] // 14) + 1
+        out[f"pos224_to_{tag}"] = np_(vs.interpolate_pos_encoding(torch.zeros(1, n, 384), hw[0], hw[1]))
+    # slice transformer layer: d_model 48, 12 heads (hd 4), masks, RoPE, both need_weights paths
+    for rot in (None, "RoPE"):
+        tag = "rope" if rot else "plain"
+        layer = tb.TransformerEncoderLayer(d_model=48, nhead=12, dim_feedforward=48, dropout=0.0,
+                                           batch_first=True, norm_first=True, rotary_positional_encoding=rot)
+        enc = nn.TransformerEncoder(layer, num_layers=1, norm=nn.LayerNorm(48)).eval()
+        sdl = {}
+        for i, (k, v) in enumerate(enc.state_dict().items()):
+            if k.endswith("freqs"):
+                sdl[k] = v.clone()
+                continue
+            sdl[k] = torch.from_numpy(synth.hash_normal(tuple(v.shape), 11, 2000 + i)) * (0.35 if v.dim() > 1 else 0.2)
+            if "norm" in k and k.endswith("weight"):
+                sdl[k] = sdl[k] + 1.0
+        enc.load_state_dict(sdl)
+        for k, v in sdl.items():
+            out[f"tel_{tag}_sd.{k}"] = np_(v)
+        x = torch.from_numpy(synth.hash_normal((2, 9, 48), 12, 3))
+        mask = torch.zeros(2, 9, dtype=torch.bool)
+        mask[1, 6:] = True
+        out[f"tel_{tag}_in"] = np_(x)
+        out[f"tel_{tag}_mask"] = mask.numpy()
+        out[f"tel_{tag}_out"] = np_(enc(x))
+        out[f"tel_{tag}_out_masked"] = np_(enc(x, src_key_padding_mask=mask))
+        mha = enc.layers[0].self_attn
+        y = enc.layers[0].norm1(x)
+        _, w = mha(y, y, y, need_weights=True, average_attn_weights=False)
+        out[f"tel_{tag}_weights"] = np_(w)
+        _, wm = mha(y, y, y, need_weights=True, average_attn_weights=False, key_padding_mask=mask)
+        out[f"tel_{tag}_weights_masked"] = np_(wm)
+    np.savez_compressed(GOLD / "ops.npz", **out)
+    print("ops", len(out), "arrays")
+
+
+def case_errors(dino, synth):
+    res = {}
+    model, _ = build(dino, synth, 0)
+    try:
+        with torch.no_grad():
+            model(torch.zeros(1, 1, 2, 512, 512))
+    except AssertionError as e:
+        res["512x512"] = {"type": "AssertionError", "message": str(e)}
+    try:
+        with torch.no_grad():
+            model(torch.zeros(1, 1, 2, 224, 230))
+    except AssertionError as e:
+        res["224x230"] = {"type": "AssertionError", "message": str(e)}
+    try:
+        dino.DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="l")
+    except AssertionError as e:
+        res["model_size_l"] = {"type": "AssertionError", "message": str(e)}
+    (GOLD / "errors.json").write_text(json.dumps(res, indent=1))
+    print(res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    dino, synth = load_reference()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    cases = {
+        "weights": lambda: (GOLD / "weights.json").write_text(json.dumps({
+            "s_seed0": synth.state_dict_digest(synth.synth_state_dict("s", 0)),
+            "s_seed1_hub518": synth.state_dict_digest(synth.synth_state_dict("s", 1, img_size=518, layerscale=True, chunked=False)),
+            "volume_1x1x2x28x28_seed3": float(synth.synth_volume((1, 1, 2, 28, 28), 3).double().sum()),
+        }, indent=1)),
+        "ops": lambda: case_ops(dino, synth),
+        "errors": lambda: case_errors(dino, synth),
+        "c1_1x16x224": lambda: case_end2end(dino, synth, "c1_1x16x224", (1, 1, 16, 224, 224), 0),
+        "b2_mask": lambda: case_end2end(dino, synth, "b2_mask", (2, 1, 6, 112, 140), 1, mask=[0, 2]),
+        "bottleneck_pos": lambda: case_end2end(dino, synth, "bottleneck_pos", (1, 1, 5, 112, 112), 2,
+                                               use_bottleneck=True, use_slice_pos_emb=True),
+        "rope": lambda: case_end2end(dino, synth, "rope", (2, 1, 7, 112, 112), 3, rotary="RoPE", mask=[3, 0]),
+        "average": lambda: case_end2end(dino, synth, "average", (2, 1, 4, 112, 112), 4, slice_fusion="average"),
+        "linear32": lambda: case_end2end(dino, synth, "linear32", (1, 1, 32, 56, 56), 5, slice_fusion="linear"),
+        "size_b": lambda: case_end2end(dino, synth, "size_b", (1, 1, 3, 112, 112), 6, model_size="b"),
+        "c3_1x64x518": lambda: case_end2end(dino, synth, "c3_1x64x518", (1, 1, 64, 518, 518), 2, chunk=8,
+                                            plane_subset=[0, 31, 63]),
+        "s504_1x4x504": lambda: case_end2end(dino, synth, "s504_1x4x504", (1, 1, 4, 504, 504), 7, chunk=4,
+                                             plane_subset=[0, 3]),
+    }
+    for name, fn in cases.items():
+        if args.only and name not in args.only:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
