@@ -132,12 +132,14 @@ typedef struct mst_vit_weights {
  * cls_probs (nullable) fp32 [n_layers_probs, n_slices, heads, N]: CLS-row softmax of the LAST
  * n_layers_probs blocks (1 is all the reference consumes: dino.py:190; depth reproduces the
  * whole `attention_maps` list, CLS rows only).
+ * full_probs (nullable) fp32 [n_layers_probs, n_slices, heads, N, N]: the complete softmax of the
+ * same blocks -- API parity for get_attention_cls (dino.py:204-212); O(N^2) memory, off by default.
  * chunk_slices: slices processed per pass (activations of one pass stay resident in the 256 MB
  * Infinity Cache); ws must hold mst_vit_workspace_bytes(...). */
 size_t mst_vit_workspace_bytes(const mst_vit_weights* w, int H, int W, int chunk_slices);
 int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int n_slices, int H, int W,
-                   float* cls_out, float* cls_probs, int n_layers_probs, int chunk_slices,
-                   void* ws, size_t ws_bytes, mst_stream_t stream);
+                   float* cls_out, float* cls_probs, float* full_probs, int n_layers_probs,
+                   int chunk_slices, void* ws, size_t ws_bytes, mst_stream_t stream);
 
 /* Across-slice transformer + head ---------------------------------------------------------- */
 typedef struct mst_fusion_weights {

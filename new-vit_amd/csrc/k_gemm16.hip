@@ -142,7 +142,7 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     static bool attr_set = false;
     auto kern = gemm16_kernel<T, EPI, OutT>;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
         attr_set = true;
     }
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;

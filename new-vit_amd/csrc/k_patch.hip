@@ -216,7 +216,7 @@ int launch_pe(const void* vol, int n, int H, int W, const void* wp, const float*
     auto kern = patch_embed_kernel<T, InT>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
         attr_set = true;
     }
     const dim3 grid((unsigned)((total + BMP - 1) / BMP), E / BNP);

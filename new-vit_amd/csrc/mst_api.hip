@@ -1,0 +1,267 @@
+// C ABI of libmst_hip.so (include/mst_hip.h): argument checking, dtype dispatch and the two
+// orchestrators -- mst_vit_encode (per-slice DINOv2 ViT) and mst_slice_fusion (across-slice
+// transformer + head).  Nothing here allocates or synchronises: every launch goes to the caller's
+// stream, scratch comes from the caller's workspace, so a caller may capture a call into a hipGraph.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mst_common.h"
+
+static thread_local char g_err[512] = "";
+
+void mst_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mst_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mst_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return MST_ELAUNCH;
+    }
+    return MST_OK;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline size_t dt_size(int dt) { return dt == MST_F32 ? 4 : 2; }
+
+extern "C" {
+
+int mst_version(void) { return 100; }
+const char* mst_last_error(void) { return g_err; }
+
+int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,
+                  int out_dtype, int64_t out_stride, int64_t rows, int cols, float eps, mst_stream_t stream) {
+    MST_CHECK_ARG(x && gamma && beta && out, "layernorm: null pointer");
+    return launch_layernorm(x, x_stride, gamma, beta, out, out_dtype, out_stride, rows, cols, eps, (hipStream_t)stream);
+}
+
+int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+             int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue, const float* gamma,
+             float col_scale, int scale_cols, mst_stream_t stream) {
+    MST_CHECK_ARG(A && W && C, "gemm: null pointer");
+    if (ab_dtype == MST_F32) {
+        MST_CHECK_ARG(c_dtype == MST_F32, "gemm: f32 operands need f32 C");
+        return launch_gemm32((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, epilogue,
+                             gamma, col_scale, scale_cols, (hipStream_t)stream);
+    }
+    return launch_gemm16(A, ab_dtype, lda, W, ldw, bias, C, c_dtype, ldc, M, N, K, epilogue, gamma, col_scale,
+                         scale_cols, (hipStream_t)stream);
+}
+
+int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, void* out,
+                  mst_stream_t stream) {
+    MST_CHECK_ARG(qkv && out, "attention: null pointer");
+    MST_CHECK_ARG(head_dim == 64, "attention: head_dim=%d unsupported (64)", head_dim);
+    if (dtype == MST_F32) return launch_attn32((const float*)qkv, n_seq, N, heads, (float*)out, (hipStream_t)stream);
+    return launch_attn16(qkv, dtype, n_seq, N, heads, out, (hipStream_t)stream);
+}
+
+int mst_attention_cls_probs(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, float* probs,
+                            mst_stream_t stream) {
+    MST_CHECK_ARG(qkv && probs, "cls_probs: null pointer");
+    return launch_cls_probs(qkv, dtype, n_seq, N, heads, head_dim, probs, (hipStream_t)stream);
+}
+
+int mst_attention_probs_full(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, float* probs,
+                             mst_stream_t stream) {
+    MST_CHECK_ARG(qkv && probs, "probs_full: null pointer");
+    return launch_probs_full(qkv, dtype, n_seq, N, heads, head_dim, probs, (hipStream_t)stream);
+}
+
+int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset, float* out,
+                         mst_stream_t stream) {
+    MST_CHECK_ARG(pos_patch && out, "pos_embed_interp: null pointer");
+    return launch_pos_interp(pos_patch, M, E, gh, gw, offset, out, (hipStream_t)stream);
+}
+
+int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const void* wp, int dtype, const float* bias,
+                    const float* prefix, int n_prefix, const float* pos_patch, int E, float* x, mst_stream_t stream) {
+    MST_CHECK_ARG(vol && wp && bias && prefix && pos_patch && x, "patch_embed: null pointer");
+    return launch_patch_embed(vol, in_dtype, n, H, W, wp, dtype, bias, prefix, n_prefix, pos_patch, E, x,
+                              (hipStream_t)stream);
+}
+
+// ---- per-slice encoder ----------------------------------------------------------------------
+// workspace carve (chunk of C slices, Mc = C*N rows):
+//   x   fp32 [Mc, E]      residual stream
+//   xn  T    [Mc, E]      LayerNorm output; reused as the attention output
+//   big T    [Mc, 4E]     qkv [Mc, 3E] during attention, then the MLP hidden [Mc, 4E]
+static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn, size_t* off_big, size_t* total) {
+    const size_t Mc = (size_t)chunk * N, E = (size_t)w->embed_dim, ts = dt_size(w->compute_dtype);
+    size_t o = 0;
+    o += align_up(Mc * E * 4, 256);
+    *off_xn = o;
+    o += align_up(Mc * E * ts, 256);
+    *off_big = o;
+    o += align_up(Mc * 4 * E * ts, 256);
+    *total = o;
+}
+
+size_t mst_vit_workspace_bytes(const mst_vit_weights* w, int H, int W, int chunk_slices) {
+    if (!w || H <= 0 || W <= 0 || chunk_slices <= 0) return 0;
+    const int N = 1 + w->num_registers + (H / 14) * (W / 14);
+    size_t a, b, t;
+    vit_carve(w, N, chunk_slices, &a, &b, &t);
+    return t;
+}
+
+int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int n_slices, int H, int W,
+                   float* cls_out, float* cls_probs, float* full_probs, int n_layers_probs, int chunk_slices,
+                   void* ws, size_t ws_bytes, mst_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MST_CHECK_ARG(w && vol && cls_out && ws, "vit_encode: null pointer");
+    MST_CHECK_ARG(w->layers && w->depth > 0, "vit_encode: no layers");
+    MST_CHECK_ARG(H > 0 && W > 0 && H % 14 == 0 && W % 14 == 0, "vit_encode: H=%d W=%d must be multiples of 14", H, W);
+    MST_CHECK_ARG(H / 14 == w->grid_h && W / 14 == w->grid_w, "vit_encode: pos_patch prepared for grid %dx%d, input is %dx%d",
+                  w->grid_h, w->grid_w, H / 14, W / 14);
+    const int E = w->embed_dim, heads = w->num_heads, dt = w->compute_dtype;
+    MST_CHECK_ARG(heads > 0 && E == heads * 64, "vit_encode: embed_dim=%d must be 64*num_heads (%d)", E, heads);
+    MST_CHECK_ARG(dt == MST_F16 || dt == MST_BF16 || dt == MST_F32, "vit_encode: bad compute dtype %d", dt);
+    MST_CHECK_ARG(n_slices > 0 && chunk_slices > 0, "vit_encode: n_slices=%d chunk=%d", n_slices, chunk_slices);
+    MST_CHECK_ARG(n_layers_probs >= 0 && n_layers_probs <= w->depth, "vit_encode: n_layers_probs=%d", n_layers_probs);
+    const int R = w->num_registers, Np = w->grid_h * w->grid_w, N = 1 + R + Np;
+    if (chunk_slices > n_slices) chunk_slices = n_slices;
+    size_t off_xn, off_big, total;
+    vit_carve(w, N, chunk_slices, &off_xn, &off_big, &total);
+    if (ws_bytes < total) {
+        mst_set_error("vit_encode: workspace %zu < %zu bytes", ws_bytes, total);
+        return MST_EWORKSPACE;
+    }
+    float* x = (float*)ws;
+    void* xn = (char*)ws + off_xn;
+    void* big = (char*)ws + off_big;
+    const size_t in_sz = dt_size(in_dtype);
+    const float qscale = 0.125f;  // head_dim^-0.5, head_dim = 64 (attention.py:48)
+
+#define RUN(call)              \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_) return rc_;   \
+    } while (0)
+
+    for (int s0 = 0; s0 < n_slices; s0 += chunk_slices) {
+        const int c = (n_slices - s0 < chunk_slices) ? n_slices - s0 : chunk_slices;
+        const int64_t Mc = (int64_t)c * N;
+        const char* v = (const char*)vol + (size_t)s0 * H * W * in_sz;
+        RUN(launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
+        for (int l = 0; l < w->depth; ++l) {
+            const mst_vit_layer* L = &w->layers[l];
+            // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
+            RUN(launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
+            RUN(mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            const int li = l - (w->depth - n_layers_probs);
+            if (cls_probs && li >= 0)
+                RUN(launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, s));
+            if (full_probs && li >= 0)
+                RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, s));
+            RUN(mst_attention(big, dt, c, N, heads, 64, xn, s));
+            RUN(mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
+            // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
+            RUN(launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
+            RUN(mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
+            RUN(mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+        }
+        // final norm, CLS rows only (vision_transformer.py:263-265,329)
+        RUN(launch_layernorm(x, (int64_t)N * E, w->norm_w, w->norm_b, cls_out + (int64_t)s0 * E, MST_F32, E, c, E, 1e-6f, s));
+    }
+    return MST_OK;
+}
+
+// ---- across-slice transformer + head ----------------------------------------------------------
+// workspace carve (fp32): eb [B*D, emb] (bottleneck out) | xs [B*L, emb] | y [B*L, emb] |
+//                         qkv [B*L, 3emb] | ao [B*L, emb] | feat [B, emb]
+size_t mst_fusion_workspace_bytes(const mst_fusion_weights* w, int B, int D) {
+    if (!w || B <= 0 || D <= 0) return 0;
+    const size_t L = (size_t)D + 1, e = (size_t)w->emb;
+    size_t o = 0;
+    o += align_up((size_t)B * D * e * 4, 256);
+    o += 4 * align_up((size_t)B * L * e * 4, 256);
+    o += align_up((size_t)B * L * 3 * e * 4, 256);
+    o += align_up((size_t)B * e * 4, 256);
+    return o;
+}
+
+int mst_slice_fusion(const mst_fusion_weights* w, const float* emb, int B, int D, const uint8_t* key_padding_mask,
+                     float* features, float* logits, float* slice_probs, void* ws, size_t ws_bytes,
+                     mst_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MST_CHECK_ARG(w && emb && features && ws, "slice_fusion: null pointer");
+    MST_CHECK_ARG(B > 0 && D > 0, "slice_fusion: B=%d D=%d", B, D);
+    const int e = w->emb, L = D + 1;
+    const size_t need = mst_fusion_workspace_bytes(w, B, D);
+    if (ws_bytes < need) {
+        mst_set_error("slice_fusion: workspace %zu < %zu bytes", ws_bytes, need);
+        return MST_EWORKSPACE;
+    }
+    char* p = (char*)ws;
+    float* eb = (float*)p;  p += align_up((size_t)B * D * e * 4, 256);
+    float* xs = (float*)p;  p += align_up((size_t)B * L * e * 4, 256);
+    float* y = (float*)p;   p += align_up((size_t)B * L * e * 4, 256);
+    float* ao = (float*)p;  p += align_up((size_t)B * L * e * 4, 256);
+    float* y2 = (float*)p;  p += align_up((size_t)B * L * e * 4, 256);
+    float* qkv = (float*)p; p += align_up((size_t)B * L * 3 * e * 4, 256);
+    float* feat = (float*)p;
+
+    const float* src = emb;
+    if (w->bottleneck_w) {  // dino.py:134-135
+        MST_CHECK_ARG(w->emb_in % 16 == 0, "slice_fusion: emb_in=%d must be a multiple of 16", w->emb_in);
+        RUN(launch_gemm32(emb, w->emb_in, w->bottleneck_w, w->emb_in, w->bottleneck_b, eb, e, (int64_t)B * D, e,
+                          w->emb_in, MST_EPI_BIAS, nullptr, 1.f, 0, s));
+        src = eb;
+    } else {
+        MST_CHECK_ARG(w->emb_in == e, "slice_fusion: emb_in=%d != emb=%d without a bottleneck", w->emb_in, e);
+    }
+
+    int F = e;  // feature width
+    if (w->fusion_type == MST_FUSION_TRANSFORMER) {
+        MST_CHECK_ARG(w->cls_token && w->in_proj_w && w->out_proj_w && w->lin1_w && w->lin2_w && w->ln1_w && w->ln2_w && w->norm_w,
+                      "slice_fusion: missing transformer weights");
+        MST_CHECK_ARG(w->num_heads > 0 && e % w->num_heads == 0, "slice_fusion: emb=%d not divisible by heads=%d", e, w->num_heads);
+        MST_CHECK_ARG(e % 16 == 0, "slice_fusion: emb=%d must be a multiple of 16", e);
+        MST_CHECK_ARG(!w->slice_pos_emb || D <= 256, "slice_fusion: slice_pos_emb holds 256 positions, D=%d", D);
+        const int hd = e / w->num_heads;
+        const int64_t ML = (int64_t)B * L;
+        RUN(launch_slice_tokens(src, w->cls_token, w->slice_pos_emb, B, D, e, xs, s));  // dino.py:140-145
+        // x = x + out_proj(attn(in_proj(norm1 x)))                 transformer_blocks.py:567,576-582
+        RUN(launch_layernorm(xs, e, w->ln1_w, w->ln1_b, y, MST_F32, e, ML, e, 1e-5f, s));
+        RUN(launch_gemm32(y, e, w->in_proj_w, e, w->in_proj_b, qkv, 3 * e, ML, 3 * e, e, MST_EPI_BIAS, nullptr, 1.f, 0, s));
+        RUN(launch_slice_attn(qkv, B, L, w->num_heads, hd, key_padding_mask, w->rope_freqs, ao, slice_probs, s));
+        RUN(launch_gemm32(ao, e, w->out_proj_w, e, w->out_proj_b, xs, e, ML, e, e, MST_EPI_RESIDUAL, nullptr, 1.f, 0, s));
+        // x = x + linear2(relu(linear1(norm2 x)))                  transformer_blocks.py:568,585-587
+        RUN(launch_layernorm(xs, e, w->ln2_w, w->ln2_b, y, MST_F32, e, ML, e, 1e-5f, s));
+        RUN(launch_gemm32(y, e, w->lin1_w, e, w->lin1_b, y2, e, ML, e, e, MST_EPI_BIAS_RELU, nullptr, 1.f, 0, s));
+        RUN(launch_gemm32(y2, e, w->lin2_w, e, w->lin2_b, xs, e, ML, e, e, MST_EPI_RESIDUAL, nullptr, 1.f, 0, s));
+        // final LayerNorm, row 0 of every volume                   dino.py:95,153
+        RUN(launch_layernorm(xs, (int64_t)L * e, w->norm_w, w->norm_b, feat, MST_F32, e, B, e, 1e-5f, s));
+    } else if (w->fusion_type == MST_FUSION_LINEAR) {  // dino.py:154-155: 'b d e -> b (d e)'
+        F = D * e;
+        feat = (float*)src;
+    } else if (w->fusion_type == MST_FUSION_AVERAGE) {  // dino.py:156-157
+        RUN(launch_mean_slices(src, B, D, e, feat, s));
+    } else {
+        mst_set_error("slice_fusion: bad fusion type %d", w->fusion_type);
+        return MST_EINVAL;
+    }
+    RUN(launch_rows_copy(feat, F, features, F, B, F, s));
+    if (logits) {  // dino.py:166
+        MST_CHECK_ARG(w->head_w && w->out_ch > 0, "slice_fusion: logits requested without a head");
+        MST_CHECK_ARG(F % 16 == 0, "slice_fusion: feature width %d must be a multiple of 16", F);
+        RUN(launch_gemm32(feat, F, w->head_w, F, w->head_b, logits, w->out_ch, B, w->out_ch, F, MST_EPI_BIAS, nullptr, 1.f, 0, s));
+    }
+    return MST_OK;
+}
+
+int mst_attention_readout(const float* cls_probs_last, const float* slice_probs, int B, int D, int heads, int N,
+                          int num_registers, int sheads, float* plane, float* slice_attn, float* maps,
+                          mst_stream_t stream) {
+    MST_CHECK_ARG(B > 0 && D > 0 && heads > 0 && N > 1 + num_registers, "readout: bad sizes");
+    return launch_readout(cls_probs_last, slice_probs, B, D, heads, N, num_registers, sheads, plane, slice_attn, maps,
+                          (hipStream_t)stream);
+}
+
+}  // extern "C"

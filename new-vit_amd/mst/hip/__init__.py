@@ -1,0 +1,219 @@
+"""ctypes binding of libmst_hip.so (C ABI: include/mst_hip.h).
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``), the current HIP
+stream and dtype tags.  There is NO fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised (the product path never routes through torch ops or the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MST_HIP_LIB", _HERE / "libmst_hip.so"))
+
+F32, F16, BF16 = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL = 0, 1, 2, 3
+FUSION_TRANSFORMER, FUSION_LINEAR, FUSION_AVERAGE = 0, 1, 2
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
+DT_NAMES = {"fp32": F32, "f32": F32, "float32": F32, "fp16": F16, "f16": F16, "float16": F16,
+            "bf16": BF16, "bfloat16": BF16}
+
+_vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+                                   "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("embed_dim", _i), ("depth", _i), ("num_heads", _i), ("num_registers", _i),
+                ("compute_dtype", _i), ("grid_h", _i), ("grid_w", _i),
+                ("patch_w", _vp), ("patch_b", _vp), ("prefix", _vp), ("pos_patch", _vp),
+                ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp)]
+
+
+class FusionWeights(C.Structure):
+    _fields_ = [("emb_in", _i), ("emb", _i), ("out_ch", _i), ("fusion_type", _i), ("num_heads", _i)] + \
+               [(n, _vp) for n in ("bottleneck_w", "bottleneck_b", "slice_pos_emb", "cls_token",
+                                   "ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
+                                   "ln2_w", "ln2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                                   "norm_w", "norm_b", "rope_freqs", "head_w", "head_b")]
+
+
+# symbol -> (restype, argtypes); tests check every symbol of include/mst_hip.h is exported
+SIGNATURES = {
+    "mst_version": (_i, []),
+    "mst_last_error": (C.c_char_p, []),
+    "mst_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _vp]),
+    "mst_gemm": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp]),
+    "mst_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
+    "mst_vit_encode": (_i, [C.POINTER(VitWeights), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "mst_fusion_workspace_bytes": (_sz, [C.POINTER(FusionWeights), _i, _i]),
+    "mst_slice_fusion": (_i, [C.POINTER(FusionWeights), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mst_attention_readout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library once; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"libmst_hip.so not found at {LIB_PATH}: build it with `python new-vit_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the MST hot path.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return (load().mst_last_error() or b"").decode()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (status {rc}): {last_error()}")
+
+
+def dt_of(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}") from None
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor must live on a HIP device (got {t.device}); the MST kernels have no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{what}: tensor must be contiguous")
+
+
+# ---- per-op wrappers (unit parity tests call these; the models call the orchestrators) --------
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+              out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    _dev(x, "layernorm")
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _check(load().mst_layernorm(ptr(x), cols, ptr(weight), ptr(bias), ptr(out), _DT[out_dtype], cols, rows, cols,
+                                eps, stream_of(x)), "mst_layernorm")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = EPI_BIAS,
+         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         gamma: Optional[torch.Tensor] = None, col_scale: float = 1.0, scale_cols: int = 0) -> torch.Tensor:
+    _dev(a, "gemm")
+    _dev(w, "gemm")
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+    _check(load().mst_gemm(ptr(a), dt_of(a), K, ptr(w), K, ptr(bias), ptr(out), dt_of(out), N, M, N, K, epilogue,
+                           ptr(gamma), col_scale, scale_cols, stream_of(a)), "mst_gemm")
+    return out
+
+
+def attention(qkv: torch.Tensor, n_seq: int, N: int, heads: int, head_dim: int = 64) -> torch.Tensor:
+    _dev(qkv, "attention")
+    out = torch.empty((n_seq * N, heads * head_dim), dtype=qkv.dtype, device=qkv.device)
+    _check(load().mst_attention(ptr(qkv), dt_of(qkv), n_seq, N, heads, head_dim, ptr(out), stream_of(qkv)), "mst_attention")
+    return out
+
+
+def attention_cls_probs(qkv: torch.Tensor, n_seq: int, N: int, heads: int, head_dim: int = 64) -> torch.Tensor:
+    _dev(qkv, "attention_cls_probs")
+    out = torch.empty((n_seq, heads, N), dtype=torch.float32, device=qkv.device)
+    _check(load().mst_attention_cls_probs(ptr(qkv), dt_of(qkv), n_seq, N, heads, head_dim, ptr(out), stream_of(qkv)),
+           "mst_attention_cls_probs")
+    return out
+
+
+def attention_probs_full(qkv: torch.Tensor, n_seq: int, N: int, heads: int, head_dim: int = 64) -> torch.Tensor:
+    _dev(qkv, "attention_probs_full")
+    out = torch.empty((n_seq, heads, N, N), dtype=torch.float32, device=qkv.device)
+    _check(load().mst_attention_probs_full(ptr(qkv), dt_of(qkv), n_seq, N, heads, head_dim, ptr(out), stream_of(qkv)),
+           "mst_attention_probs_full")
+    return out
+
+
+def pos_embed_interp(pos_patch: torch.Tensor, M: int, gh: int, gw: int, offset: float = 0.1) -> torch.Tensor:
+    _dev(pos_patch, "pos_embed_interp")
+    E = pos_patch.shape[-1]
+    out = torch.empty((gh * gw, E), dtype=torch.float32, device=pos_patch.device)
+    _check(load().mst_pos_embed_interp(ptr(pos_patch), M, E, gh, gw, offset, ptr(out), stream_of(pos_patch)),
+           "mst_pos_embed_interp")
+    return out
+
+
+def patch_embed(vol: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, prefix: torch.Tensor,
+                pos_patch: torch.Tensor) -> torch.Tensor:
+    _dev(vol, "patch_embed")
+    n, H, W = vol.shape
+    E = wp.shape[0]
+    n_prefix = prefix.shape[0]
+    N = n_prefix + (H // 14) * (W // 14)
+    x = torch.empty((n, N, E), dtype=torch.float32, device=vol.device)
+    _check(load().mst_patch_embed(ptr(vol), dt_of(vol), n, H, W, ptr(wp), dt_of(wp), ptr(bias), ptr(prefix), n_prefix,
+                                  ptr(pos_patch), E, ptr(x), stream_of(vol)), "mst_patch_embed")
+    return x
+
+
+def vit_workspace_bytes(w: VitWeights, H: int, W: int, chunk: int) -> int:
+    return int(load().mst_vit_workspace_bytes(C.byref(w), H, W, chunk))
+
+
+def vit_encode(w: VitWeights, vol: torch.Tensor, cls_out: torch.Tensor, cls_probs: Optional[torch.Tensor],
+               n_layers_probs: int, chunk: int, ws: torch.Tensor, full_probs: Optional[torch.Tensor] = None):
+    _dev(vol, "vit_encode")
+    n, H, W = vol.shape
+    _check(load().mst_vit_encode(C.byref(w), ptr(vol), dt_of(vol), n, H, W, ptr(cls_out), ptr(cls_probs),
+                                 ptr(full_probs), n_layers_probs, chunk, ptr(ws), ws.numel() * ws.element_size(),
+                                 stream_of(vol)), "mst_vit_encode")
+
+
+def fusion_workspace_bytes(w: FusionWeights, B: int, D: int) -> int:
+    return int(load().mst_fusion_workspace_bytes(C.byref(w), B, D))
+
+
+def slice_fusion(w: FusionWeights, emb: torch.Tensor, B: int, D: int, mask: Optional[torch.Tensor],
+                 features: torch.Tensor, logits: Optional[torch.Tensor], slice_probs: Optional[torch.Tensor],
+                 ws: torch.Tensor):
+    _dev(emb, "slice_fusion")
+    _check(load().mst_slice_fusion(C.byref(w), ptr(emb), B, D, ptr(mask), ptr(features), ptr(logits), ptr(slice_probs),
+                                   ptr(ws), ws.numel() * ws.element_size(), stream_of(emb)), "mst_slice_fusion")
+
+
+def attention_readout(cls_probs_last: Optional[torch.Tensor], slice_probs: Optional[torch.Tensor], B: int, D: int,
+                      heads: int, N: int, num_registers: int, sheads: int, plane: Optional[torch.Tensor],
+                      slice_attn: Optional[torch.Tensor], maps: Optional[torch.Tensor]):
+    t = cls_probs_last if cls_probs_last is not None else slice_probs
+    _check(load().mst_attention_readout(ptr(cls_probs_last), ptr(slice_probs), B, D, heads, N, num_registers, sheads,
+                                        ptr(plane), ptr(slice_attn), ptr(maps), stream_of(t)), "mst_attention_readout")

@@ -1,0 +1,165 @@
+"""End-to-end parity of the drop-in DinoV2ClassifierSlice on an MI355X against the fixtures the
+REFERENCE produced (tests/golden, tools/gen_golden.py) and against the CPU oracle.
+
+Tolerances (floating point; north_star: logits / attention maps within 1e-3 in fp32):
+  fp32 mode  (exact fp32 MFMA)            logits 1e-4 abs, embeddings 2e-4 rel-L2, maps 1e-3 rel-L2
+  fp16 mode  (TF32-class operands)        logits 1e-3 abs, embeddings 3e-3 rel-L2, maps 2e-2 rel-L2
+  bf16 mode  (bench dtype, 8-bit mantissa) logits 3e-2 abs, embeddings 3e-2 rel-L2, maps 1.5e-1 rel-L2
+Attention maps are compared relatively (entries are ~1/(D*Np): an absolute 1e-3 would be vacuous).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_l2
+from mst import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {  # mode -> (logits abs, emb rel, maps rel)
+    "fp32": (1e-4, 2e-4, 1e-3),
+    "fp16": (1e-3, 3e-3, 2e-2),
+    "bf16": (3e-2, 3e-2, 1.5e-1),
+}
+CASES = {
+    "c1_1x16x224": dict(),
+    "b2_mask": dict(),
+    "bottleneck_pos": dict(use_bottleneck=True, use_slice_pos_emb=True),
+    "rope": dict(rotary_positional_encoding="RoPE"),
+    "average": dict(slice_fusion="average"),
+    "linear32": dict(slice_fusion="linear"),
+    "size_b": dict(model_size="b"),
+}
+
+
+def build(name_kwargs, seed, mode, **extra):
+    from mst.models import DinoV2ClassifierSlice
+    kw = dict(name_kwargs)
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode, **kw, **extra)
+    sd = synth.synth_state_dict(kw.get("model_size", "s"), seed,
+                                use_bottleneck=kw.get("use_bottleneck", False),
+                                use_slice_pos_emb=kw.get("use_slice_pos_emb", False),
+                                slice_fusion=kw.get("slice_fusion", "transformer"),
+                                rotary=kw.get("rotary_positional_encoding"))
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference_fixture(name, mode):
+    g = load_golden(name)
+    tl, te, tm = TOL[mode]
+    model = build(CASES[name], int(g["seed"]), mode)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"]) if "src_key_padding_mask" in g else None
+    with torch.no_grad():
+        logits = model(src, src_key_padding_mask=mask)                 # CPU input: forward moves it (dino.py:121)
+        feats = model(src.cuda(), src_key_padding_mask=mask, without_linear=True)
+    assert logits.shape == g["logits"].shape and logits.is_cuda
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
+    assert rel_l2(feats.cpu(), g["features"]) < te * 2
+    B, _, D, H, W = src.shape
+    with torch.no_grad():
+        emb, _, _ = model.encode_slices(src.cuda().reshape(B * D, H, W))
+    assert rel_l2(emb.cpu(), g["emb"]) < te
+    if "attention_maps" not in g:
+        return
+    with torch.no_grad():
+        logits2 = model(src, save_attn=True, src_key_padding_mask=mask)
+    assert torch.equal(logits2, logits)                               # save_attn must not change the logits
+    assert len(model.attention_maps) == 12 and model.attention_maps[-1].shape[2] == 1
+    rows = torch.stack([m[:, :, 0] for m in model.attention_maps]).cpu()
+    assert rel_l2(rows, g["vit_cls_rows"]) < tm
+    assert rel_l2(model.attention_maps_slice[-1].cpu(), g["slice_map"]) < tm
+    for _ in range(2):                                                # getters are idempotent
+        assert rel_l2(model.get_plane_attention().cpu(), g["plane_attention"]) < tm
+        sa = model.get_slice_attention()
+        assert sa.shape == (B * D, 1, 1)
+        assert rel_l2(sa.cpu(), g["slice_attention"]) < tm
+        am = model.get_attention_maps()
+        assert am.shape == g["attention_maps"].shape
+        assert rel_l2(am.cpu(), g["attention_maps"]) < tm
+    assert abs(float(model.get_attention_maps().sum()) - B * model.encoder.num_heads) < 1e-2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_c3_full_size_volume_matches_reference_fixture(mode):
+    """BASELINE config 3 shape: 1 x 64 x 518 x 518 (the legal realisation of '512^2') with attention."""
+    g = load_golden("c3_1x64x518")
+    tl, te, tm = TOL[mode]
+    model = build({}, int(g["seed"]), mode)
+    src = synth.synth_volume((1, 1, 64, 518, 518), int(g["seed"]) + 100)
+    with torch.no_grad():
+        logits = model(src.cuda(), save_attn=True)
+        emb, _, _ = model.encode_slices(src.cuda().reshape(64, 518, 518))
+    assert rel_l2(emb.cpu(), g["emb"]) < te
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
+    sub = g["plane_subset"].tolist()
+    assert rel_l2(model.get_slice_attention().cpu(), g["slice_attention"]) < tm
+    assert rel_l2(model.get_plane_attention().cpu()[sub], g["plane_attention"]) < tm
+    assert rel_l2(model.get_attention_maps().cpu()[sub], g["attention_maps"]) < tm
+
+
+def test_504_grid_and_chunking_are_consistent():
+    """504^2 (36x36 grid, interpolated pos-embed) vs the reference fixture; chunked == unchunked bit-for-bit."""
+    g = load_golden("s504_1x4x504")
+    src = synth.synth_volume((1, 1, 4, 504, 504), int(g["seed"]) + 100).cuda()
+    m1 = build({}, int(g["seed"]), "fp32")
+    m2 = build({}, int(g["seed"]), "fp32", chunk_slices=3)
+    with torch.no_grad():
+        l1, l2 = m1(src), m2(src)
+    assert np.abs(l1.cpu().numpy() - g["logits"]).max() < 1e-4
+    assert torch.equal(l1, l2)
+
+
+def test_properties_slice_permutation_and_batch_independence():
+    """Size-independent properties at a shape the oracle does not cover: volumes of a batch are
+    independent, and without slice position information the logits are invariant to slice order."""
+    model = build({}, 5, "fp16")
+    a = synth.synth_volume((1, 1, 6, 112, 154), 11).cuda()
+    b = synth.synth_volume((1, 1, 6, 112, 154), 12).cuda()
+    with torch.no_grad():
+        la, lb = model(a), model(b)
+        lab = model(torch.cat([a, b], 0))
+        perm = torch.tensor([3, 1, 5, 0, 2, 4], device="cuda")
+        lp = model(a[:, :, perm])
+    assert torch.allclose(lab, torch.cat([la, lb], 0), atol=1e-5)
+    assert torch.allclose(lp, la, atol=2e-5)
+
+
+def test_error_behaviour_matches_reference():
+    ref = json.loads((GOLDEN / "errors.json").read_text())
+    model = build({}, 0, "bf16")
+    with pytest.raises(AssertionError) as e:
+        model(torch.zeros(1, 1, 2, 512, 512))
+    assert str(e.value) == ref["512x512"]["message"]
+    with pytest.raises(AssertionError) as e:
+        model(torch.zeros(1, 1, 2, 224, 230))
+    assert str(e.value) == ref["224x230"]["message"]
+    from mst.models import DinoV2ClassifierSlice
+    with pytest.raises(AssertionError) as e:
+        DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="l")
+    assert str(e.value) == ref["model_size_l"]["message"]
+
+
+def test_hub_layout_layerscale_registers_against_oracle():
+    """Hub key layout (blocks.<i>, ls gammas, 518 pos-embed) + 4 register tokens: checked against the
+    CPU oracle (the reference cannot build this configuration offline: it needs torch.hub)."""
+    from oracle import mst_oracle as O
+    from mst.models.dino import _ViT
+    from mst.models import DinoV2ClassifierSlice
+    sd = synth.synth_state_dict("s", 9, img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp32", use_registers=True)
+    model.encoder = _ViT(384, 12, 6, img_size=518, num_register_tokens=4, layerscale=1.0, chunked=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    src = synth.synth_volume((1, 1, 3, 70, 98), 21)
+    with torch.no_grad():
+        logits = model(src, save_attn=True)
+        ref = O.forward(sd, src, keep="cls")
+    assert np.abs(logits.cpu().numpy() - ref["logits"].numpy()).max() < 1e-4
+    assert rel_l2(model.get_plane_attention().cpu(), O.plane_attention(ref["vit_maps"][-1], 4)) < 1e-3
+    assert rel_l2(model.get_attention_maps().cpu(), O.attention_maps(ref["vit_maps"][-1], ref["slice_map"], 4)) < 1e-3

@@ -117,8 +117,8 @@ def test_ops_slice_transformer_layer(tag):
         O.SLICE_HEADS = old
     assert np.abs(y.numpy() - g[f"tel_{tag}_out"]).max() < 1e-5
     assert np.abs(ym.numpy() - g[f"tel_{tag}_out_masked"]).max() < 1e-5
-    assert np.abs(w.numpy() - g[f"tel_{tag}_weights"]).max() < 1e-6
-    assert np.abs(wm.numpy() - g[f"tel_{tag}_weights_masked"]).max() < 1e-6
+    assert np.abs(w.numpy() - g[f"tel_{tag}_weights"]).max() < 5e-6
+    assert np.abs(wm.numpy() - g[f"tel_{tag}_weights_masked"]).max() < 5e-6
 
 
 def test_error_fixture_messages():
