@@ -180,6 +180,18 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
                           int heads, int N, int num_registers, int sheads, float* plane,
                           float* slice_attn, float* maps, mst_stream_t stream);
 
+/* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only; off by
+ * default).  When enabled, every launch is bracketed by hipEventRecord on the call's own stream;
+ * mst_profile_collect waits for the recorded events, returns the accumulated milliseconds and
+ * launch counts per kernel kind since the last collect, and resets.  Process-global state. */
+enum mst_kernel_kind {
+    MST_K_PATCH_EMBED = 0, MST_K_LAYERNORM = 1, MST_K_GEMM_QKV = 2, MST_K_ATTENTION = 3,
+    MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_COUNT = 8
+};
+int mst_profile_enable(int on);
+int mst_profile_collect(double* ms_total, int64_t* launches); /* arrays of MST_K_COUNT */
+const char* mst_kernel_kind_name(int kind);
+
 #ifdef __cplusplus
 }
 #endif

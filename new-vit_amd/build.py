@@ -18,7 +18,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "build"
-LIB = HERE / "mst" / "hip" / "libmst_hip.so"
+LIB = Path(os.environ.get("MST_BUILD_LIB", HERE / "mst" / "hip" / "libmst_hip.so"))   # ablation builds: other name
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
@@ -38,7 +38,12 @@ def newer(src: Path, dst: Path, deps) -> bool:
 
 
 def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> Path:
+    global OBJ
     cc = hipcc()
+    extra = os.environ.get("MST_EXTRA_FLAGS", "").split()
+    if extra:                     # ablation / diagnostic builds get their own object directory
+        OBJ = HERE / ("build_" + "_".join(f.strip("-").replace("=", "") for f in extra))
+        FLAGS.extend(f for f in extra if f not in FLAGS)
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "mst_hip.h", Path(__file__)]
     srcs = sorted(CSRC.glob("*.hip"))

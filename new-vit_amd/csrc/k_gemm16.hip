@@ -10,6 +10,10 @@
 // 1-D grid with an XCD-aware remap: tiles that share an A panel run on one XCD's L2.
 //
 // Reference arithmetic: F.linear at attention.py:58,67; mlp.py:35-38; block.py:90-94.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "mst_common.h"
 
 namespace {
@@ -58,11 +62,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
         }
     };
 
+    // accumulators start at the bias (no bias load / vmcnt drain left in the epilogue)
     f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias) b0 = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + i * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = b0;
+    }
 
     const int sw = (lane >> 1) & 7;  // ((row >> 1) & 7) for row = 16*k + (lane & 15)
     const int a_row_off = (wm * 64 + (lane & 15)) * 128;
@@ -93,46 +101,61 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
         }
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*64+i*16+(lane>>4)*4
+    // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*64+i*16+(lane>>4)*4.
+    // Interior tiles run branch-free (per-lane `m < M` branches make hipcc drain vmcnt(0) before every store).
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
-        float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (EPI == MST_EPI_RESIDUAL && gamma) gv = *reinterpret_cast<const float4*>(gamma + n);
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+            float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (EPI == MST_EPI_RESIDUAL && gamma) gv = *reinterpret_cast<const float4*>(gamma + n);
+            float sc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-            if (m >= M) continue;
-            float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r < scale_cols) v[r] *= col_scale;
-                if (EPI == MST_EPI_BIAS_GELU) v[r] = gelu_erf(v[r]);
-                if (EPI == MST_EPI_BIAS_RELU) v[r] = fmaxf(v[r], 0.f);
-            }
-            OutT* cp = C + (int64_t)m * ldc + n;
+            for (int r = 0; r < 4; ++r) sc[r] = (n + r < scale_cols) ? col_scale : 1.0f;
+            float4 xv[4];
             if constexpr (EPI == MST_EPI_RESIDUAL) {
-                float4 xv = *reinterpret_cast<const float4*>(cp);
-                xv.x += gv.x * v[0];
-                xv.y += gv.y * v[1];
-                xv.z += gv.z * v[2];
-                xv.w += gv.w * v[3];
-                *reinterpret_cast<float4*>(cp) = xv;
-            } else if constexpr (sizeof(OutT) == 4) {
-                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                typedef __attribute__((ext_vector_type(4))) OutT o4;
-                o4 pk;
-                pk[0] = (OutT)v[0];
-                pk[1] = (OutT)v[1];
-                pk[2] = (OutT)v[2];
-                pk[3] = (OutT)v[3];
-                *reinterpret_cast<o4*>(cp) = pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+                    if (FULL || m < M) xv[j] = *reinterpret_cast<const float4*>(C + (int64_t)m * ldc + n);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+                if (!FULL && m >= M) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] *= sc[r];
+                    if (EPI == MST_EPI_BIAS_GELU) v[r] = (sizeof(OutT) == 2) ? gelu_fast(v[r]) : gelu_erf(v[r]);
+                    if (EPI == MST_EPI_BIAS_RELU) v[r] = fmaxf(v[r], 0.f);
+                }
+                OutT* cp = C + (int64_t)m * ldc + n;
+                if constexpr (EPI == MST_EPI_RESIDUAL) {
+                    float4 o;
+                    o.x = xv[j].x + gv.x * v[0];
+                    o.y = xv[j].y + gv.y * v[1];
+                    o.z = xv[j].z + gv.z * v[2];
+                    o.w = xv[j].w + gv.w * v[3];
+                    *reinterpret_cast<float4*>(cp) = o;
+                } else if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) OutT o4;
+                    o4 pk;
+                    pk[0] = (OutT)v[0];
+                    pk[1] = (OutT)v[1];
+                    pk[2] = (OutT)v[2];
+                    pk[3] = (OutT)v[3];
+                    *reinterpret_cast<o4*>(cp) = pk;
+                }
             }
         }
-    }
+    };
+    if (m0 + BM <= M) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 template <typename T, int EPI, typename OutT>
@@ -186,6 +209,11 @@ int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw
     MST_CHECK_ARG(cdt == MST_F32 || cdt == dt, "gemm16: C dtype must be f32 or the operand dtype");
     MST_CHECK_ARG(epi != MST_EPI_RESIDUAL || cdt == MST_F32, "gemm16: residual epilogue needs f32 C");
     if (M <= 0) return MST_OK;
+    static const bool big_ok = !(getenv("MST_GEMM_BIG") && atoi(getenv("MST_GEMM_BIG")) == 0);
+    // measured on MI355X (tools/bench_gemm.py): the read-modify-write epilogue of the residual GEMMs is
+    // HBM-bound and overlaps better with two small workgroups per CU; the others favour the big tile
+    if (big_ok && epi != MST_EPI_RESIDUAL && gemm16_big_applicable(M, N, K))
+        return launch_gemm16_big(A, dt, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     if (dt == MST_BF16) return dispatch<bf16_t>(A, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     if (dt == MST_F16) return dispatch<f16_t>(A, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     mst_set_error("gemm16: bad operand dtype %d", dt);

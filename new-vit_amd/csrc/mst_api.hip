@@ -26,6 +26,38 @@ int mst_check_launch(const char* what) {
     return MST_OK;
 }
 
+// ---- optional per-kernel event timing (bench only) -------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_used, g_prof_free;
+const char* const kKindNames[MST_K_COUNT] = {"patch_embed", "layernorm", "gemm_qkv", "attention",
+                                             "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs"};
+struct ProfScope {
+    ProfRec r{};
+    bool on = false;
+    hipStream_t s;
+    ProfScope(int kind, hipStream_t st) : s(st) {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+        else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+        r.kind = kind;
+        on = true;
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_used.push_back(r);
+    }
+};
+}  // namespace
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline size_t dt_size(int dt) { return dt == MST_F32 ? 4 : 2; }
 
@@ -143,28 +175,37 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         int rc_ = (call);      \
         if (rc_) return rc_;   \
     } while (0)
+#define RUNK(kind, call)             \
+    do {                             \
+        int rc_;                     \
+        {                            \
+            ProfScope ps_(kind, s);  \
+            rc_ = (call);            \
+        }                            \
+        if (rc_) return rc_;         \
+    } while (0)
 
     for (int s0 = 0; s0 < n_slices; s0 += chunk_slices) {
         const int c = (n_slices - s0 < chunk_slices) ? n_slices - s0 : chunk_slices;
         const int64_t Mc = (int64_t)c * N;
         const char* v = (const char*)vol + (size_t)s0 * H * W * in_sz;
-        RUN(launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
+        RUNK(MST_K_PATCH_EMBED, launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
         for (int l = 0; l < w->depth; ++l) {
             const mst_vit_layer* L = &w->layers[l];
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
-            RUN(launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
-            RUN(mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
+            RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             const int li = l - (w->depth - n_layers_probs);
             if (cls_probs && li >= 0)
-                RUN(launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, s));
+                RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, s));
             if (full_probs && li >= 0)
                 RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, s));
-            RUN(mst_attention(big, dt, c, N, heads, 64, xn, s));
-            RUN(mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
+            RUNK(MST_K_ATTENTION, mst_attention(big, dt, c, N, heads, 64, xn, s));
+            RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
             // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
-            RUN(launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
-            RUN(mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
-            RUN(mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+            RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
+            RUNK(MST_K_GEMM_FC1, mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
+            RUNK(MST_K_GEMM_FC2, mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
         }
         // final norm, CLS rows only (vision_transformer.py:263-265,329)
         RUN(launch_layernorm(x, (int64_t)N * E, w->norm_w, w->norm_b, cls_out + (int64_t)s0 * E, MST_F32, E, c, E, 1e-6f, s));
@@ -263,5 +304,31 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
     return launch_readout(cls_probs_last, slice_probs, B, D, heads, N, num_registers, sheads, plane, slice_attn, maps,
                           (hipStream_t)stream);
 }
+
+int mst_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return MST_OK;
+}
+
+int mst_profile_collect(double* ms_total, int64_t* launches) {
+    MST_CHECK_ARG(ms_total && launches, "profile_collect: null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int k = 0; k < MST_K_COUNT; ++k) { ms_total[k] = 0.0; launches[k] = 0; }
+    for (const ProfRec& r : g_prof_used) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            mst_set_error("profile_collect: event query failed");
+            return MST_ELAUNCH;
+        }
+        ms_total[r.kind] += ms;
+        launches[r.kind] += 1;
+        g_prof_free.push_back(r);
+    }
+    g_prof_used.clear();
+    return MST_OK;
+}
+
+const char* mst_kernel_kind_name(int kind) { return (kind >= 0 && kind < MST_K_COUNT) ? kKindNames[kind] : "?"; }
 
 }  // extern "C"

@@ -62,6 +62,21 @@ __device__ __forceinline__ float gelu_erf(float v) {  // nn.GELU() exact form (m
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 
+// GELU for 16-bit outputs: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 on erf, <= 5e-7 abs /
+// 2e-4 rel on gelu: far below one fp16/bf16 ulp), one v_rcp + one v_exp instead of libm erff.
+// The negative branch multiplies by the complementary term directly (no 1 - erf cancellation).
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float pe = p * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);  // = erfc(z)
+    const float h = 0.5f * v;
+    return v >= 0.f ? h * (2.0f - pe) : h * pe;
+}
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
 // so give each XCD a contiguous run of tile ids (neighbouring tiles share operand panels in its L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -87,6 +102,10 @@ int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b,
 int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
                   void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+bool gemm16_big_applicable(int64_t M, int N, int K);
+int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                      void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
+                      float col_scale, int scale_cols, hipStream_t s);
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);

@@ -64,7 +64,11 @@ SIGNATURES = {
     "mst_fusion_workspace_bytes": (_sz, [C.POINTER(FusionWeights), _i, _i]),
     "mst_slice_fusion": (_i, [C.POINTER(FusionWeights), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mst_attention_readout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mst_profile_enable": (_i, [_i]),
+    "mst_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
+K_COUNT = 8
 
 _lib: Optional[C.CDLL] = None
 
@@ -217,3 +221,16 @@ def attention_readout(cls_probs_last: Optional[torch.Tensor], slice_probs: Optio
     t = cls_probs_last if cls_probs_last is not None else slice_probs
     _check(load().mst_attention_readout(ptr(cls_probs_last), ptr(slice_probs), B, D, heads, N, num_registers, sheads,
                                         ptr(plane), ptr(slice_attn), ptr(maps), stream_of(t)), "mst_attention_readout")
+
+
+def profile_enable(on: bool):
+    _check(load().mst_profile_enable(1 if on else 0), "mst_profile_enable")
+
+
+def profile_collect():
+    """{kind name: (total ms, launches)} since the last collect (waits for the recorded events)."""
+    ms = (C.c_double * K_COUNT)()
+    cnt = (C.c_int64 * K_COUNT)()
+    _check(load().mst_profile_collect(ms, cnt), "mst_profile_collect")
+    lib = load()
+    return {lib.mst_kernel_kind_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(K_COUNT)}

@@ -146,6 +146,7 @@ class _SelfAttn(_Params):
         self.in_proj_weight = nn.Parameter(torch.empty(3 * E, E))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * E))
         self.out_proj = _lin(E, E)
+        assert E % SLICE_HEADS == 0, "embed_dim must be divisible by num_heads"   # nn.MultiheadAttention
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
         if rotary == "RoPE":  # transformer_blocks.py:333-349 (theta 256, 'lang' freqs)
