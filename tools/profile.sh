@@ -1,0 +1,10 @@
+#!/bin/bash
+# rocprofv3 kernel-trace summary of the default bench command (run on the GPU box via gpurun).
+# Usage: bash tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/ ; copy the *_kernel_stats.csv to profiles/
+set -e
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_stdout.json 2> $OUT/bench_stderr.log
+ls -R $OUT | head -30
