@@ -49,6 +49,7 @@ def kernel_flops(kind: str, n_slices: int, N: int) -> float:
         "gemm_proj": 2.0 * M * E * E,
         "gemm_fc1": 2.0 * M * 4 * E * E,
         "gemm_fc2": 2.0 * M * 4 * E * E,
+        "mlp_fused": 4.0 * M * 4 * E * E,
     }.get(kind, 0.0)
 
 

@@ -52,7 +52,8 @@ const char* mst_last_error(void); /* thread-local message of the last failing ca
 
 /* nn.LayerNorm over the last dim: block.py:63,75; vision_transformer.py:165,263 (eps 1e-6);
  * transformer_blocks.py:499-500, dino.py:95 (eps 1e-5).  x fp32 [rows, cols] with row stride
- * x_stride (elements); out dtype f32/f16/bf16 with row stride out_stride.  cols even, <= 1024. */
+ * x_stride (elements); out dtype f32/f16/bf16 with row stride out_stride.  cols even, <= 1024.
+ * gamma == beta == NULL: normalise only (the affine is folded into the consumer's weights). */
 int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta,
                   void* out, int out_dtype, int64_t out_stride, int64_t rows, int cols, float eps,
                   mst_stream_t stream);
@@ -103,6 +104,19 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
                     const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
                     int E, float* x, mst_stream_t stream);
 
+/* Fused MLP half of a ViT block (block.py:93-94,113; mlp.py:34-40), E = 384, 16-bit operands:
+ *   x[M,E] (fp32, in place) += ls2 * (fc2(gelu(fc1(normalise(x)))) + b2);  xn_out (nullable, dtype) = normalise(x_new)
+ * normalise = LayerNorm without affine (eps).  The hidden activations stay on chip.
+ * wpack: 48 chunks x 49152 B, chunk c = LDS image of W1f rows [32c,32c+32) and W2 columns [32c,32c+32):
+ *   W1 part  [ks 0..11][h 0..31][slot 0..3][8]  = W1f[32c+h][32ks + 8(slot^f(h)) ..+7],   f(r) = (-(r>>2))&3
+ *   W2 part  [R 0..383][slot 0..3][8]           = W2[n(R)][32c + phys(slot^f(R), 0..7)]
+ *     n(R)      = 32((R>>4)>>1) + 8((R&15)>>2) + 4((R>>4)&1) + (R&3)
+ *     phys(c,j) = j<4 ? 4c+j : 16+4c+(j-4)
+ *   W1f = fc1_w * ln2_w (columns);  b1f (fp32, 1536+32 padded) = fc1_b + fc1_w . ln2_b;  b2 = fc2 bias.
+ * (new-vit_amd/mst/models/dino.py::_pack_mlp builds it.) */
+int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2,
+                  const float* ls2, int64_t M, int E, float eps, mst_stream_t stream);
+
 /* Whole per-slice encoder ------------------------------------------------------------------ */
 typedef struct mst_vit_layer {
     const float* ln1_w; const float* ln1_b;       /* block.py:63  */
@@ -113,6 +127,12 @@ typedef struct mst_vit_layer {
     const void* fc1_w;  const float* fc1_b;       /* mlp.py:28  [4E,E] */
     const void* fc2_w;  const float* fc2_b;       /* mlp.py:30  [E,4E] */
     const float* ls2;
+    /* Optional fused-LayerNorm form (16-bit modes, E = 384).  When mlp_pack != NULL for every layer the
+     * encoder runs  normalise -> QKV(qkv_wf, qkv_bf) -> attention -> proj -> mst_mlp_fused  per block:
+     *   qkv_wf = qkv_w * ln1_w (columns), qkv_bf = qkv_b + qkv_w . ln1_b            (norm1 folded)
+     *   mlp_pack / fc1_bf: see mst_mlp_fused                                          (norm2 folded) */
+    const void* qkv_wf; const float* qkv_bf;
+    const void* mlp_pack; const float* fc1_bf;
 } mst_vit_layer;
 
 typedef struct mst_vit_weights {
@@ -186,7 +206,8 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
  * launch counts per kernel kind since the last collect, and resets.  Process-global state. */
 enum mst_kernel_kind {
     MST_K_PATCH_EMBED = 0, MST_K_LAYERNORM = 1, MST_K_GEMM_QKV = 2, MST_K_ATTENTION = 3,
-    MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_COUNT = 8
+    MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_MLP_FUSED = 8,
+    MST_K_COUNT = 9
 };
 int mst_profile_enable(int on);
 int mst_profile_collect(double* ms_total, int64_t* launches); /* arrays of MST_K_COUNT */

@@ -19,8 +19,11 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "build"
 LIB = Path(os.environ.get("MST_BUILD_LIB", HERE / "mst" / "hip" / "libmst_hip.so"))   # ablation builds: other name
+# -amdgpu-mfma-vgpr-form: keep MFMA C/D in VGPRs (gfx950's register file is unified).  hipcc's default put the
+# attention scores in AGPRs and spent 127 v_accvgpr_read/write per KV tile moving them to the softmax and back.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+PER_FILE_FLAGS = {"k_attn16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "k_attn32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc() -> str:
@@ -50,7 +53,7 @@ def build(force: bool = False, jobs: int = 8, verbose: bool = True) -> Path:
     todo = [s for s in srcs if force or newer(s, OBJ / (s.stem + ".o"), headers)]
 
     def compile_one(src: Path):
-        cmd = [cc, *FLAGS, "-c", str(src), "-o", str(OBJ / (src.stem + ".o"))]
+        cmd = [cc, *FLAGS, *PER_FILE_FLAGS.get(src.name, []), "-c", str(src), "-o", str(OBJ / (src.stem + ".o"))]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r
 

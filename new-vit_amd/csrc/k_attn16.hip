@@ -15,6 +15,8 @@
 // q arrives pre-scaled by head_dim^-0.5 (folded into the QKV projection epilogue).
 //
 // Reference arithmetic: attention.py:56-66 (and dino.py:226-243 for the stored probabilities).
+#include <type_traits>
+
 #include "mst_common.h"
 
 namespace {
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
     lstore(0);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    // one KV tile; MASK = the ragged last tile (keys >= N get -inf).  Peeled so the 32 selects per tile that the
+    // compiler otherwise if-converts into EVERY iteration stay out of the steady-state loop.
+    auto tile_step = [&](auto mask_tag, int t) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         const int buf = t & 1;
         if (t + 1 < nt) gload(t + 1);
         if (wave_active) {
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
                     s[kb] = mfma32(a, bq[ds], s[kb]);
                 }
             }
-            if (t == nt - 1 && (N & 63)) {  // mask keys >= N (wave-uniform branch)
+            if constexpr (MASK) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -178,7 +183,10 @@ __global__ __launch_bounds__(256) void attn16_kernel(const T* __restrict__ qkv, 
         }
         if (t + 1 < nt) lstore(buf ^ 1);
         __syncthreads();
-    }
+    };
+    const int nt_full = (N & 63) ? nt - 1 : nt;
+    for (int t = 0; t < nt_full; ++t) tile_step(std::false_type{}, t);
+    if (nt_full < nt) tile_step(std::true_type{}, nt - 1);
 
     if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -44,8 +44,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < NJ; ++j) {
         const int c = j * 128 + lane * 2;
         if (c < cols) {
-            const float2 gg = *reinterpret_cast<const float2*>(g + c);
-            const float2 bb = *reinterpret_cast<const float2*>(b + c);
+            float2 gg = make_float2(1.f, 1.f), bb = make_float2(0.f, 0.f);
+            if (g) {   // g == b == nullptr: normalise only
+                gg = *reinterpret_cast<const float2*>(g + c);
+                bb = *reinterpret_cast<const float2*>(b + c);
+            }
             const float y0 = (v[j].x - mean) * rstd * gg.x + bb.x;
             const float y1 = (v[j].y - mean) * rstd * gg.y + bb.y;
             if constexpr (sizeof(OutT) == 4) {

@@ -35,7 +35,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_used, g_prof_free;
 const char* const kKindNames[MST_K_COUNT] = {"patch_embed", "layernorm", "gemm_qkv", "attention",
-                                             "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs"};
+                                             "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs", "mlp_fused"};
 struct ProfScope {
     ProfRec r{};
     bool on = false;
@@ -68,7 +68,7 @@ const char* mst_last_error(void) { return g_err; }
 
 int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,
                   int out_dtype, int64_t out_stride, int64_t rows, int cols, float eps, mst_stream_t stream) {
-    MST_CHECK_ARG(x && gamma && beta && out, "layernorm: null pointer");
+    MST_CHECK_ARG(x && out && ((gamma != nullptr) == (beta != nullptr)), "layernorm: null pointer");
     return launch_layernorm(x, x_stride, gamma, beta, out, out_dtype, out_stride, rows, cols, eps, (hipStream_t)stream);
 }
 
@@ -116,6 +116,12 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
     MST_CHECK_ARG(vol && wp && bias && prefix && pos_patch && x, "patch_embed: null pointer");
     return launch_patch_embed(vol, in_dtype, n, H, W, wp, dtype, bias, prefix, n_prefix, pos_patch, E, x,
                               (hipStream_t)stream);
+}
+
+int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2,
+                  const float* ls2, int64_t M, int E, float eps, mst_stream_t stream) {
+    MST_CHECK_ARG(x && wpack && b1f && b2, "mlp_fused: null pointer");
+    return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2, ls2, M, E, eps, (hipStream_t)stream);
 }
 
 // ---- per-slice encoder ----------------------------------------------------------------------
@@ -190,11 +196,20 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         const int64_t Mc = (int64_t)c * N;
         const char* v = (const char*)vol + (size_t)s0 * H * W * in_sz;
         RUNK(MST_K_PATCH_EMBED, launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
+        // fused-LayerNorm pipeline (16-bit, E = 384): norm1 folded into QKV, norm2 + MLP in one kernel
+        bool fused = (dt != MST_F32) && E == 384;
+        for (int l = 0; l < w->depth && fused; ++l)
+            fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
+        if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
         for (int l = 0; l < w->depth; ++l) {
             const mst_vit_layer* L = &w->layers[l];
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
-            RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
-            RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            if (fused) {
+                RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            } else {
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            }
             const int li = l - (w->depth - n_layers_probs);
             if (cls_probs && li >= 0)
                 RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, s));
@@ -203,9 +218,13 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             RUNK(MST_K_ATTENTION, mst_attention(big, dt, c, N, heads, 64, xn, s));
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
             // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
-            RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
-            RUNK(MST_K_GEMM_FC1, mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
-            RUNK(MST_K_GEMM_FC2, mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+            if (fused) {
+                RUNK(MST_K_MLP_FUSED, launch_mlp16(x, (l + 1 < w->depth) ? xn : nullptr, dt, L->mlp_pack, L->fc1_bf, L->fc2_b, L->ls2, Mc, E, 1e-6f, s));
+            } else {
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUNK(MST_K_GEMM_FC1, mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
+                RUNK(MST_K_GEMM_FC2, mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+            }
         }
         // final norm, CLS rows only (vision_transformer.py:263-265,329)
         RUN(launch_layernorm(x, (int64_t)N * E, w->norm_w, w->norm_b, cls_out + (int64_t)s0 * E, MST_F32, E, c, E, 1e-6f, s));

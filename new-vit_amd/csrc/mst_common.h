@@ -77,6 +77,26 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return v >= 0.f ? h * (2.0f - pe) : h * pe;
 }
 
+// Transcendental-free GELU for 16-bit outputs inside MFMA-dense loops: erf(z) = z*P(z^2) on |z| <= 3.2 (degree-8
+// Chebyshev fit, |erf err| <= 8e-5, |gelu err| <= 1.8e-4 absolute: below one fp16/bf16 ulp of O(1) activations),
+// saturating to +-1 beyond.  9 FMAs + 5 simple ops, no v_exp / v_rcp (quarter-rate issue).
+__device__ __forceinline__ float gelu_poly(float v) {
+    const float z = fminf(fabsf(v) * 0.70710678118654752440f, 3.2f);
+    const float u = z * z;
+    float p = 3.263779068761133e-08f;
+    p = fmaf(p, u, -1.673741012956179e-06f);
+    p = fmaf(p, u, 3.751051790327989e-05f);
+    p = fmaf(p, u, -0.000488409298395181f);
+    p = fmaf(p, u, 0.0041668641449124355f);
+    p = fmaf(p, u, -0.025040875590456917f);
+    p = fmaf(p, u, 0.11119564373069263f);
+    p = fmaf(p, u, -0.37554270907102755f);
+    p = fmaf(p, u, 1.1283444184507676f);
+    const float e = fminf(p * z, 1.0f);            // erf(|v|/sqrt2)
+    const float h = 0.5f * v;
+    return fmaf(fabsf(h), e, h);                   // 0.5 v (1 + sign(v) erf) = h + |h| e
+}
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
 // so give each XCD a contiguous run of tile ids (neighbouring tiles share operand panels in its L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -109,6 +129,8 @@ int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, const float* ls2,
+                 int64_t M, int E, float eps, hipStream_t s);
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s);
 int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
 int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,

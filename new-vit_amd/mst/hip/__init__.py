@@ -30,7 +30,8 @@ _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-                                   "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                   "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
+                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf")]
 
 
 class VitWeights(C.Structure):
@@ -58,6 +59,7 @@ SIGNATURES = {
     "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
     "mst_vit_encode": (_i, [C.POINTER(VitWeights), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -68,7 +70,7 @@ SIGNATURES = {
     "mst_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
-K_COUNT = 8
+K_COUNT = 9
 
 _lib: Optional[C.CDLL] = None
 
@@ -188,6 +190,44 @@ def patch_embed(vol: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, prefix:
     _check(load().mst_patch_embed(ptr(vol), dt_of(vol), n, H, W, ptr(wp), dt_of(wp), ptr(bias), ptr(prefix), n_prefix,
                                   ptr(pos_patch), E, ptr(x), stream_of(vol)), "mst_patch_embed")
     return x
+
+
+def mlp_fused(x: torch.Tensor, wpack: torch.Tensor, b1f: torch.Tensor, b2: torch.Tensor, ls2: Optional[torch.Tensor],
+              xn_out: Optional[torch.Tensor], dtype: torch.dtype, eps: float = 1e-6):
+    """x [M,384] fp32 updated in place; xn_out (optional, `dtype`) receives normalise(x_new)."""
+    _dev(x, "mlp_fused")
+    M, E = x.shape
+    _check(load().mst_mlp_fused(ptr(x), ptr(xn_out), _DT[dtype], ptr(wpack), ptr(b1f), ptr(b2), ptr(ls2), M, E, eps,
+                                stream_of(x)), "mst_mlp_fused")
+
+
+def pack_mlp(fc1_w, fc1_b, fc2_w, ln_w, ln_b, dtype: torch.dtype):
+    """Host-side packing of one MLP for mst_mlp_fused (layout: include/mst_hip.h).  Inputs fp32 tensors on any
+    device: fc1_w [1536,384], fc1_b [1536], fc2_w [384,1536], ln_w/ln_b [384].  Returns (wpack [48,24576] dtype,
+    b1f [1568] fp32)."""
+    dev = fc1_w.device
+    w1f = fc1_w.float() * ln_w.float()[None, :]
+    b1f = fc1_b.float() + fc1_w.float() @ ln_b.float()
+    ar = lambda n: torch.arange(n, device=dev)
+    # W1 image: [chunk][ks][h][slot][8]
+    w1c = w1f.view(48, 32, 12, 4, 8).permute(0, 2, 1, 3, 4)                    # [chunk, ks, h, c, j]
+    fh = (-(ar(32) >> 2)) & 3
+    cidx = ar(4)[None, :] ^ fh[:, None]                                         # [h, slot] -> c
+    w1img = w1c[:, :, ar(32)[:, None], cidx, :]                                 # [chunk, ks, h, slot, 8]
+    # W2 image: [chunk][R][slot][8]
+    p = ar(32); c = p >> 3; j = p & 7
+    phys = torch.where(j < 4, 4 * c + j, 16 + 4 * c + j - 4)
+    R = ar(384); t = R >> 4; i = R & 15
+    nphys = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3)
+    w2p = fc2_w.float().view(384, 48, 32)[:, :, phys][nphys]                    # [R, chunk, p]
+    w2c = w2p.permute(1, 0, 2).reshape(48, 384, 4, 8)                           # [chunk, R, c, j]
+    fR = (-(R >> 2)) & 3
+    cidxR = ar(4)[None, :] ^ fR[:, None]
+    w2img = w2c[:, R[:, None], cidxR, :]                                        # [chunk, R, slot, 8]
+    wpack = torch.cat([w1img.reshape(48, -1), w2img.reshape(48, -1)], dim=1).to(dtype).contiguous()
+    b1p = torch.zeros(1536 + 32, device=dev, dtype=torch.float32)
+    b1p[:1536] = b1f
+    return wpack, b1p
 
 
 def vit_workspace_bytes(w: VitWeights, H: int, W: int, chunk: int) -> int:

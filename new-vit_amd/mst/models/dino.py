@@ -321,6 +321,19 @@ class DinoV2ClassifierSlice(BasicClassifier):
             L.fc1_w, L.fc1_b = hip.ptr(cmp(b.mlp.fc1.weight)), hip.ptr(f32(b.mlp.fc1.bias))
             L.fc2_w, L.fc2_b = hip.ptr(cmp(b.mlp.fc2.weight)), hip.ptr(f32(b.mlp.fc2.bias))
             L.ls2 = hip.ptr(f32(b.ls2.gamma)) if hasattr(b, "ls2") else None
+            if cdt != hip.F32 and E == 384:
+                # fused-LayerNorm form: norm1 folded into QKV, norm2 folded into the packed MLP (mst_mlp_fused)
+                with torch.no_grad():
+                    g1 = b.norm1.weight.detach().to(dev, torch.float32)
+                    be1 = b.norm1.bias.detach().to(dev, torch.float32)
+                    wq = b.attn.qkv.weight.detach().to(dev, torch.float32)
+                    L.qkv_wf = hip.ptr(cmp(wq * g1[None, :]))
+                    L.qkv_bf = hip.ptr(f32(b.attn.qkv.bias.detach().to(dev, torch.float32) + wq @ be1))
+                    wpack, b1p = hip.pack_mlp(b.mlp.fc1.weight.detach().to(dev), b.mlp.fc1.bias.detach().to(dev),
+                                              b.mlp.fc2.weight.detach().to(dev), b.norm2.weight.detach().to(dev),
+                                              b.norm2.bias.detach().to(dev), tdt)
+                    keep.extend([wpack, b1p])
+                    L.mlp_pack, L.fc1_bf = hip.ptr(wpack), hip.ptr(b1p)
         vit = hip.VitWeights()
         vit.embed_dim, vit.depth, vit.num_heads, vit.num_registers = E, enc.depth, enc.num_heads, R
         vit.compute_dtype = cdt

@@ -169,6 +169,36 @@ def test_gemm_rejects_bad_shapes(hip):
         hip.gemm(torch.zeros(8, 64), torch.zeros(128, 64), None)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,with_ls,with_xn", [(16, False, True), (300, True, True), (128 * 300 + 5, False, False), (41000, True, True)])
+def test_mlp_fused(hip, dt, M, with_ls, with_xn):
+    """LN2 -> fc1 -> GELU -> fc2 -> residual (+ next normalise) in one kernel vs an fp64 reference of the
+    reference's block arithmetic (block.py:93-94; mlp.py:34-40).  Operand rounding is the kernel's own (weights,
+    normalised rows and hidden activations in `dt`), so the tolerance is that of a 16-bit GEMM chain."""
+    tdt = DT[dt]
+    E, Hd = 384, 1536
+    x = rnd((M, E), 50, 1.5) + 0.3
+    w1, b1 = rnd((Hd, E), 51) / math.sqrt(E), rnd((Hd,), 52) * 0.1
+    w2, b2 = rnd((E, Hd), 53) / math.sqrt(Hd), rnd((E,), 54) * 0.1
+    g, be = rnd((E,), 55) * 0.2 + 1, rnd((E,), 56) * 0.2
+    ls = (rnd((E,), 57) * 0.3 + 1) if with_ls else None
+    wpack, b1p = hip.pack_mlp(w1.cuda(), b1.cuda(), w2.cuda(), g.cuda(), be.cuda(), tdt)
+    xc = x.cuda().clone()
+    xn = torch.empty(M, E, dtype=tdt, device="cuda") if with_xn else None
+    hip.mlp_fused(xc, wpack, b1p, b2.cuda(), None if ls is None else ls.cuda(), xn, tdt)
+    xd = x.double()
+    h = torch.nn.functional.layer_norm(xd, (E,), g.double(), be.double(), 1e-6)
+    h = h @ w1.double().t() + b1.double()
+    h = 0.5 * h * (1 + torch.erf(h / math.sqrt(2)))
+    y = h @ w2.double().t() + b2.double()
+    ref = xd + (ls.double() if ls is not None else 1.0) * y
+    tol = {"bf16": 1.5e-2, "fp16": 2.5e-3}[dt]
+    assert float((xc.double().cpu() - ref).abs().max() / y.abs().max()) < tol
+    if with_xn:
+        refn = torch.nn.functional.layer_norm(ref, (E,))
+        assert float((xn.double().cpu() - refn).abs().max()) < tol * 4
+
+
 # ---------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, n, N, heads, hd):
     q, k, v = qkv.double().reshape(n, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
