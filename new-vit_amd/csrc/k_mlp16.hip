@@ -5,20 +5,23 @@
 // token the kernel moves ~3x1536 B in + 1536 B (+768 B) out instead of ~12 KB for LN + fc1 + fc2 as three launches
 // (the unfused layer is HBM-bound: DESIGN.md section 5).
 //
-// Structure (persistent, one 8-wave workgroup per CU, 128 token rows per tile):
-//   * waves work in PAIRS on 32 rows: both keep the 32 normalised rows as GEMM1 B-operand fragments in registers
-//     (LN affine folded into W1 / b1 on the host); wave `hf` of a pair computes hidden units [16hf, 16hf+16) of
-//     each 32-wide chunk (GEMM1) and output columns [192hf, 192hf+192) (GEMM2), so every weight fragment read from
-//     LDS feeds TWO MFMAs (one fragment per MFMA saturates the LDS read port: measured on the first version);
-//   * the GELU'd GEMM1 accumulators, converted in place, ARE GEMM2's B operand; the two half-fragments of a pair
-//     are swapped through a 16 KB LDS buffer (same lane index on both sides); GEMM2 runs one chunk behind GEMM1,
-//     so one `s_barrier` per chunk orders both the weight ring and the swap, and the GELU hides under MFMAs;
+// Structure: persistent, one 8-wave workgroup per CU, 128 token rows per tile, PRODUCER / CONSUMER wave roles
+// (waves w and w+4 share a SIMD, so each SIMD hosts one of each and their instruction mixes complement):
+//   * producer k (waves 0-3): LayerNorm of rows [32k, 32k+32) kept as GEMM1 B-operand fragments in registers (the
+//     LN affine is folded into W1 / b1 on the host); per 32-wide hidden chunk 48 MFMAs (H^T = W1c . xhat^T),
+//     GELU on 16 values per lane, and the accumulators -- converted in place, they ARE GEMM2's B operand -- go to
+//     a 2 KB LDS slot at the lane's own index;
+//   * consumer k (waves 4-7): one chunk behind, 48 MFMAs per chunk (y^T[384 x 32] += W2c . H^T, 192 accumulator
+//     registers), all LDS-DMA issue, and per tile the epilogue x += ls2*(y + b2) plus the next LayerNorm straight
+//     from the registers -- while the producers already normalise the next tile;
+//   * every weight fragment read from LDS feeds two MFMAs; reads are hand-pipelined DEPTH ahead behind counted
+//     lgkmcnt waits (hipcc otherwise emits read -> wait(0) -> 2 MFMAs);
 //   * weights stream through two 3-deep LDS rings (W1 rows / W2 columns of a chunk, 24 KB each), pre-packed on the
-//     host as the exact swizzled LDS image (every LDS-DMA piece is 1 KiB contiguous); one DMA group stays in
-//     flight behind counted `s_waitcnt vmcnt(6)`; b1 travels in registers one chunk ahead of its use;
-//   * W2's columns are permuted on the host to the accumulator's k order and its rows so that a lane ends up
-//     with 8-column groups (128-B row segments across the 4 lane groups) for the residual read-modify-write;
-//   * epilogue: x += ls2*(y + b2); next LayerNorm from the registers (pair-wise statistics through LDS).
+//     host as the exact swizzled LDS image (1 KiB contiguous per LDS-DMA piece); the rings run across tile
+//     boundaries; one step's DMA group stays in flight behind `s_waitcnt vmcnt(12)`; ONE `s_barrier` per step orders
+//     ring slots and the H hand-off;
+//   * W2's columns are permuted on the host to the accumulator's k order and its rows so that a lane ends up with
+//     8-column groups (128-B row segments across the 4 lane groups) for the residual read-modify-write.
 #include <type_traits>
 
 #include "mst_common.h"
@@ -32,18 +35,17 @@ constexpr int W2_BYTES = E * CH * 2;                    // 24 KiB
 constexpr int CHUNK_BYTES = W1_BYTES + W2_BYTES;        // packed weights per chunk in global memory
 constexpr int NSLOT = 3;
 constexpr int W2_RING = NSLOT * W1_BYTES;               // byte offset of the W2 ring
-constexpr int HBUF = 2 * NSLOT * W1_BYTES;              // byte offset of the pair-swap buffer (2 x 8 KiB)
+constexpr int HBUF = 2 * NSLOT * W1_BYTES;              // byte offset of the H hand-off buffer (2 x 8 KiB)
 constexpr int LDS_BYTES = HBUF + 2 * 8192;              // 163,840 = all of the LDS
 constexpr int KS = E / 32;                              // 12 k-steps of GEMM1
-constexpr int NTH = E / 32;                             // 12 output tiles (of 16 columns) per wave
+constexpr int NT = E / 16;                              // 24 output tiles (16 columns) of GEMM2
+constexpr int PC = 12;                                  // LDS-DMA pieces per consumer wave per step
+constexpr int DEPTH = 4;                                // fragment reads in flight ahead of the MFMAs
 
-// ---- hand-pipelined LDS fragment reads.  hipcc schedules `ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs` 24 times per
-// chunk here (LDS latency fully exposed); the reads are therefore issued as asm, DEPTH ahead of their MFMAs, behind
-// counted lgkmcnt waits, each wait followed by sched_barrier(0) so no MFMA is hoisted above it (cdna guide rule 18).
 template <int OFF, typename V> __device__ __forceinline__ void lds_read_b128(V& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
-template <int N> __device__ __forceinline__ void wait_lgkm() {
+template <int N> __device__ __forceinline__ void wait_lgkm() {       // + fence: no MFMA above the wait (rule 18)
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -53,15 +55,23 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
         static_for<I + 1, N>(f);
     }
 }
-constexpr int DEPTH = 4;
 
-template <int N> __device__ __forceinline__ void wait_vm_barrier() {
-#ifdef ABL_NOBAR
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-#endif
+#ifdef MLP_STAMPS
+// diagnostic build only (never shipped): per-wave cycle sums of the step phases, read back by mst_debug_mlp_stamps
+__device__ unsigned long long g_stamps[256 * 8 * 4];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
+#define STAMP(var) const unsigned long long var = stamp()
+#define ACCUM(slot, a, b) st[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define ACCUM(slot, a, b)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __restrict__ xn_out,
@@ -69,220 +79,257 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                                                     const float* __restrict__ b1f, const float* __restrict__ b2,
                                                     const float* __restrict__ ls2, int M, int ntiles, float eps) {
     typedef typename V8<T>::type vec8;
-    typedef typename V8<T>::half_type vec4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pr = wave >> 1, hf = wave & 1;
+    const bool producer = wave < 4;
+    const int pr = wave & 3;                             // rows [32*pr, 32*pr + 32) of the tile
     const int frow = lane & 15, g = lane >> 4;
     const int fslot = (g ^ ((0 - (frow >> 2)) & 3)) * 16;
-    const int w1_off = (16 * hf + frow) * 64 + fslot;              // + ks*2048 within a W1 slot
-    const int w2_off = (16 * (NTH * hf) + frow) * 64 + fslot;      // + tt*1024 within a W2 slot
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    char* const hmine = smem + HBUF + ((pr * 2 + 0) * 2 + hf) * 512 + lane * 8;        // + mt*1024 + parity*8192
-    char* const hother = smem + HBUF + ((pr * 2 + 0) * 2 + (hf ^ 1)) * 512 + lane * 8;
+    const int frag_off = frow * 64 + fslot;              // + 1024*tile16 (+ ks*2048 in the W1 image)
+    char* const hslot = smem + HBUF + pr * 2048 + lane * 16;       // + mt*1024 + parity*8192
 
-    // LDS-DMA: a half-chunk (W1 or W2 image, 24 pieces of 1 KiB) = 3 pieces per wave
-    auto dma_half = [&](const char* src, char* dst) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src + (wave * 3 + u) * 1024 + lane * 16),
-                                             LDS_PTR(dst + (wave * 3 + u) * 1024), 16, 0, 0);
-    };
-    auto dma_w1 = [&](int c) { dma_half(wpack + (size_t)c * CHUNK_BYTES, smem + (c % NSLOT) * W1_BYTES); };
-    auto dma_w2 = [&](int c) { dma_half(wpack + (size_t)c * CHUNK_BYTES + W1_BYTES, smem + W2_RING + (c % NSLOT) * W2_BYTES); };
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int last = my_tiles * NCHUNK;                  // steps 0 .. last; producers work in [0,last), consumers in [1,last]
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // weight stream of this tile: W1(0), W1(1), W2(0) now; then one group {W1(c+2), W2(c+1)} per chunk
-        dma_w1(0);
-        dma_w1(1);
-        dma_w2(0);
-
-        const int mrow = tile * 128 + pr * 32 + frow;   // rows mrow and mrow + 16
-        // ---- LayerNorm statistics and the GEMM1 B-operand fragments (normalised rows, 16-bit)
-        vec8 xa[2][KS];
-        float mean_old[2];
+    // DMA group of step s: everything step s+2 needs = W1 image of producer chunk (s+2)%48 -> W1 slot (s+2)%3 and
+    // W2 image of the chunk consumers see at step s+2, i.e. (s+1)%48 -> W2 slot (s+2)%3.  Issued by consumers only.
+    auto dma_group = [&](int s) {
+        const int sp = s + 2;
+        const int slot = sp % NSLOT;
+        const char* s1 = wpack + (size_t)(sp % NCHUNK) * CHUNK_BYTES;
+        const char* s2 = wpack + (size_t)((sp + NCHUNK - 1) % NCHUNK) * CHUNK_BYTES + W1_BYTES;
+        const bool has1 = sp < last, has2 = (sp >= 1) && (sp <= last);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = mrow + 16 * mt;
-            const float* xr = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
-            float v[KS * 8];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4 a = *reinterpret_cast<const float4*>(xr + 32 * ks);
-                const float4 b = *reinterpret_cast<const float4*>(xr + 32 * ks + 4);
-                v[8 * ks + 0] = a.x; v[8 * ks + 1] = a.y; v[8 * ks + 2] = a.z; v[8 * ks + 3] = a.w;
-                v[8 * ks + 4] = b.x; v[8 * ks + 5] = b.y; v[8 * ks + 6] = b.z; v[8 * ks + 7] = b.w;
+        for (int u = 0; u < PC; ++u) {
+            const int p = pr * PC + u;                   // piece 0..47: 0..23 = W1 image, 24..47 = W2 image
+            if (p < 24) {
+                if (has1) __builtin_amdgcn_global_load_lds(GLB_PTR(s1 + p * 1024 + lane * 16),
+                                                           LDS_PTR(smem + slot * W1_BYTES + p * 1024), 16, 0, 0);
+            } else {
+                if (has2) __builtin_amdgcn_global_load_lds(GLB_PTR(s2 + (p - 24) * 1024 + lane * 16),
+                                                           LDS_PTR(smem + W2_RING + slot * W2_BYTES + (p - 24) * 1024), 16, 0, 0);
             }
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < KS * 8; ++i) sum += v[i];
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.0f / E);
-            float sq = 0.f;
-#pragma unroll
-            for (int i = 0; i < KS * 8; ++i) { const float d = v[i] - mean; sq = fmaf(d, d, sq); }
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * (1.0f / E) + eps);
-            mean_old[mt] = mean;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xa[mt][ks][j] = (T)((v[8 * ks + j] - mean) * rstd);
         }
-        // ---- GEMM2 accumulators start at b2: tile tt, register r <-> column 192*hf + 32*(tt>>1) + 8*g + 4*(tt&1) + r
-        const int col0 = 192 * hf + 8 * g;
-        f32x4 acc[NTH][2];
-#pragma unroll
-        for (int tt = 0; tt < NTH; ++tt) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col0 + 32 * (tt >> 1) + 4 * (tt & 1));
-            acc[tt][0] = bv;
-            acc[tt][1] = bv;
-        }
-        f32x4 bias_next = *reinterpret_cast<const f32x4*>(b1f + 16 * hf + 4 * g);   // b1 of chunk 0
+    };
+    if (!producer) {
+        dma_group(-2);
+        dma_group(-1);
+    }
 
-        vec4 hown[2];                                    // this wave's GELU'd half-fragments of the previous chunk
+    // The two roles run two separate step loops (same number of s_barriers: one per step 0..last), so the
+    // register allocator sees the producer's fragments and the consumer's accumulators in disjoint live ranges.
+    // barrier(s): the DMA group of step s-2 has landed (consumers waited for theirs) and every H(s-1) is written.
+#define ACC(t, mt) R[2 * (t) + (mt)]
+#define XA(mt, ks) R[KS * (mt) + (ks)]
+    if (producer) {
+        u32x4 R[2 * KS];                                 // xa[mt][ks]: normalised rows, GEMM1 B operand
+        f32x4 bias_next[2];
+        bias_next[0] = *reinterpret_cast<const f32x4*>(b1f + 4 * g);
+        bias_next[1] = *reinterpret_cast<const f32x4*>(b1f + 16 + 4 * g);
+#ifdef MLP_STAMPS
+        unsigned long long st[4] = {0, 0, 0, 0};
+#endif
 #pragma unroll 1
-        for (int c = 0; c <= NCHUNK; ++c) {
-            // barrier(c): W1(c) and W2(c-1) have landed for every wave; every wave wrote its H(c-1) halves
-            if (c == 0) wait_vm_barrier<0>();
-            else if (c < NCHUNK - 1) wait_vm_barrier<6>();
-            else if (c == NCHUNK - 1) wait_vm_barrier<3>();
-            else wait_vm_barrier<0>();
-            const f32x4 bias_cur = bias_next;
-#ifndef ABL_NOBIAS
-            if (c + 1 < NCHUNK) bias_next = *reinterpret_cast<const f32x4*>(b1f + (c + 1) * CH + 16 * hf + 4 * g);
-#endif
-#ifndef ABL_NOLOAD
-            if (c + 2 < NCHUNK) dma_w1(c + 2);          // slot of W1(c-1): free since barrier(c)
-            if (c + 1 < NCHUNK) dma_w2(c + 1);          // slot of W2(c-2): free since barrier(c)
-#endif
-            // ---- GEMM2 of chunk c-1 (operands complete since the barrier)
-            if (c >= 1) {
-                const int par = (c - 1) & 1;
-                vec8 hfrag[2];
+        for (int s = 0; s <= last; ++s) {
+            STAMP(t0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // H(s-1) writes drained before the hand-off
+            STAMP(t1);
+            ACCUM(0, t0, t1);
+            if (s < last) {
+                const int c = s % NCHUNK;
+                if (c == 0) {
+                    // ---- LayerNorm of this pair's 32 rows of tile s/48 -> GEMM1 B-operand fragments
+                    const int tile = blockIdx.x + (s / NCHUNK) * gridDim.x;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int m = tile * 128 + pr * 32 + 16 * mt + frow;
+                        const float* xr = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
+                        float v[KS * 8];
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const float4 a = *reinterpret_cast<const float4*>(xr + 32 * ks);
+                            const float4 b = *reinterpret_cast<const float4*>(xr + 32 * ks + 4);
+                            v[8 * ks + 0] = a.x; v[8 * ks + 1] = a.y; v[8 * ks + 2] = a.z; v[8 * ks + 3] = a.w;
+                            v[8 * ks + 4] = b.x; v[8 * ks + 5] = b.y; v[8 * ks + 6] = b.z; v[8 * ks + 7] = b.w;
+                        }
+                        float sum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < KS * 8; ++i) sum += v[i];
+                        sum += __shfl_xor(sum, 16, 64);
+                        sum += __shfl_xor(sum, 32, 64);
+                        const float mean = sum * (1.0f / E);
+                        float sq = 0.f;
+#pragma unroll
+                        for (int i = 0; i < KS * 8; ++i) { const float d = v[i] - mean; sq = fmaf(d, d, sq); }
+                        sq += __shfl_xor(sq, 16, 64);
+                        sq += __shfl_xor(sq, 32, 64);
+                        const float rstd = rsqrtf(sq * (1.0f / E) + eps);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                        {
+                            vec8 t8;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t8[j] = (T)((v[8 * ks + j] - mean) * rstd);
+                            XA(mt, ks) = __builtin_bit_cast(u32x4, t8);
+                        }
+                    }
+                }
+                STAMP(t2);
+                ACCUM(1, t1, t2);                        // LayerNorm prologue (c == 0 only)
+                // ---- GEMM1 of chunk c: 32 hidden units x 32 rows (accumulators start at b1), GELU, hand-off
+                const f32x4 b0 = bias_next[0], b1v = bias_next[1];
+                {
+                    const int cn = (c + 1) % NCHUNK;     // b1 of the next step's chunk, one step ahead
+                    bias_next[0] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 4 * g);
+                    bias_next[1] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 16 + 4 * g);
+                }
+                f32x4 h[2][2] = {{b0, b0}, {b1v, b1v}};  // [hidden tile][row tile]
+                const unsigned w1a = lds_base + (s % NSLOT) * W1_BYTES + frag_off;
+                vec8 w[2 * KS];                          // fragment index q = 2*ks + ht  ->  byte offset ks*2048 + ht*1024
+                wait_lgkm<0>();
+                static_for<0, DEPTH>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<(q >> 1) * 2048 + (q & 1) * 1024>(w[q], w1a); });
+                static_for<0, 2 * KS>([&](auto i) {
+                    constexpr int q = decltype(i)::value;
+                    if constexpr (q + DEPTH < 2 * KS) lds_read_b128<((q + DEPTH) >> 1) * 2048 + ((q + DEPTH) & 1) * 1024>(w[q + DEPTH], w1a);
+                    wait_lgkm<(2 * KS - 1 - q < DEPTH) ? (2 * KS - 1 - q) : DEPTH>();
+                    h[q & 1][0] = mfma16(w[q], __builtin_bit_cast(vec8, XA(0, q >> 1)), h[q & 1][0]);
+                    h[q & 1][1] = mfma16(w[q], __builtin_bit_cast(vec8, XA(1, q >> 1)), h[q & 1][1]);
+                });
+                STAMP(t3);
+                ACCUM(2, t2, t3);                        // GEMM1
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const vec4 oth = *reinterpret_cast<const vec4*>(hother + mt * 1024 + par * 8192);
-                    const vec4 lo = hf ? oth : hown[mt], hi = hf ? hown[mt] : oth;
+                    vec8 hv;                             // k order of GEMM2 = (hidden tile, register) order of GEMM1
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hfrag[mt][j] = lo[j];
-                        hfrag[mt][4 + j] = hi[j];
+                    for (int r = 0; r < 4; ++r) {
+                        hv[r] = (T)gelu_poly(h[0][mt][r]);
+                        hv[4 + r] = (T)gelu_poly(h[1][mt][r]);
                     }
+                    *reinterpret_cast<vec8*>(hslot + mt * 1024 + (s & 1) * 8192) = hv;
                 }
-                const unsigned w2a = lds_base + W2_RING + ((c - 1) % NSLOT) * W2_BYTES + w2_off;
-                vec8 w2[NTH];
-                wait_lgkm<0>();
-                static_for<0, DEPTH>([&](auto i) { lds_read_b128<decltype(i)::value * 1024>(w2[decltype(i)::value], w2a); });
-                static_for<0, NTH>([&](auto i) {
-                    constexpr int tt = decltype(i)::value;
-                    if constexpr (tt + DEPTH < NTH) lds_read_b128<(tt + DEPTH) * 1024>(w2[tt + DEPTH], w2a);
-                    wait_lgkm<(NTH - 1 - tt < DEPTH) ? (NTH - 1 - tt) : DEPTH>();
-#ifdef ABL_NOMFMA
-                    asm volatile("" ::"v"(w2[tt]));
-#else
-                    acc[tt][0] = mfma16(w2[tt], hfrag[0], acc[tt][0]);
-                    acc[tt][1] = mfma16(w2[tt], hfrag[1], acc[tt][1]);
-#endif
-                });
-            }
-            // ---- GEMM1 of chunk c: this wave's 16 hidden units x 32 rows, then GELU and the pair swap
-            if (c < NCHUNK) {
-                f32x4 h0 = bias_cur, h1 = bias_cur;
-                const unsigned w1a = lds_base + (c % NSLOT) * W1_BYTES + w1_off;
-                vec8 w1[KS];
-                wait_lgkm<0>();
-                static_for<0, DEPTH>([&](auto i) { lds_read_b128<decltype(i)::value * 2048>(w1[decltype(i)::value], w1a); });
-                static_for<0, KS>([&](auto i) {
-                    constexpr int ks = decltype(i)::value;
-                    if constexpr (ks + DEPTH < KS) lds_read_b128<(ks + DEPTH) * 2048>(w1[ks + DEPTH], w1a);
-                    wait_lgkm<(KS - 1 - ks < DEPTH) ? (KS - 1 - ks) : DEPTH>();
-#ifdef ABL_NOMFMA
-                    asm volatile("" ::"v"(w1[ks]));
-#else
-                    h0 = mfma16(w1[ks], xa[0][ks], h0);
-                    h1 = mfma16(w1[ks], xa[1][ks], h1);
-#endif
-                });
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hown[0][r] = (T)gelu_poly(h0[r]);
-                    hown[1][r] = (T)gelu_poly(h1[r]);
-                }
-                *reinterpret_cast<vec4*>(hmine + (c & 1) * 8192) = hown[0];
-                *reinterpret_cast<vec4*>(hmine + 1024 + (c & 1) * 8192) = hown[1];
+                STAMP(t4);
+                ACCUM(3, t3, t4);                        // GELU + hand-off
             }
         }
-
-        // ---- epilogue: residual (+ LayerScale) on this wave's 192 columns, then the next LayerNorm
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = mrow + 16 * mt;
-            float* xw = x + (size_t)(m < M ? m : M - 1) * E + col0;
-            float4 xo[NTH];
-#pragma unroll
-            for (int tt = 0; tt < NTH; ++tt) xo[tt] = *reinterpret_cast<const float4*>(xw + 32 * (tt >> 1) + 4 * (tt & 1));
-#pragma unroll
-            for (int tt = 0; tt < NTH; ++tt) {
-                float4 gs = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (ls2) gs = *reinterpret_cast<const float4*>(ls2 + col0 + 32 * (tt >> 1) + 4 * (tt & 1));
-                f32x4& a = acc[tt][mt];
-                a[0] = xo[tt].x + gs.x * a[0];
-                a[1] = xo[tt].y + gs.y * a[1];
-                a[2] = xo[tt].z + gs.z * a[2];
-                a[3] = xo[tt].w + gs.w * a[3];
-                if (m < M) *reinterpret_cast<float4*>(xw + 32 * (tt >> 1) + 4 * (tt & 1)) = make_float4(a[0], a[1], a[2], a[3]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {            // shifted one-pass statistics (shift = the row's old mean)
-                    const float d = a[r] - mean_old[mt];
-                    s1[mt] += d;
-                    s2[mt] = fmaf(d, d, s2[mt]);
-                }
-            }
-        }
-        asm volatile("s_barrier" ::: "memory");          // every wave is done with the rings and the swap buffer
-        if (xn_out) {
-            // pair-wise row statistics through LDS: stat[pr][hf][mt][frow] (after the 4 lane groups are folded)
-            float* stat = reinterpret_cast<float*>(smem + HBUF);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                s1[mt] += __shfl_xor(s1[mt], 16, 64); s1[mt] += __shfl_xor(s1[mt], 32, 64);
-                s2[mt] += __shfl_xor(s2[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
-                if (g == 0) {
-                    stat[(((pr * 2 + hf) * 2 + mt) * 16 + frow) * 2 + 0] = s1[mt];
-                    stat[(((pr * 2 + hf) * 2 + mt) * 16 + frow) * 2 + 1] = s2[mt];
-                }
-            }
+#ifdef MLP_STAMPS
+        if (lane == 0) for (int i = 0; i < 4; ++i) g_stamps[(blockIdx.x * 8 + wave) * 4 + i] = st[i];
+#endif
+    } else {
+        u32x4 R[2 * NT];                                 // acc[t][mt]: y^T accumulators
+#ifdef MLP_STAMPS
+        unsigned long long st[4] = {0, 0, 0, 0};
+#endif
+#pragma unroll 1
+        for (int s = 0; s <= last; ++s) {
+            STAMP(t0);
+            if (s >= 2 && s <= last - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            STAMP(t1);
+            ACCUM(0, t0, t1);                            // DMA wait + barrier
+            dma_group(s);
+            STAMP(t2);
+            ACCUM(1, t1, t2);                            // DMA issue
+            if (s >= 1) {
+                const int sc = s - 1, c = sc % NCHUNK;
+                if (c == 0) {                            // new tile: accumulators start at b2
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float o1 = stat[(((pr * 2 + (hf ^ 1)) * 2 + mt) * 16 + frow) * 2 + 0];
-                const float o2 = stat[(((pr * 2 + (hf ^ 1)) * 2 + mt) * 16 + frow) * 2 + 1];
-                const float d1 = (s1[mt] + o1) * (1.0f / E);
-                const float var = (s2[mt] + o2) * (1.0f / E) - d1 * d1;
-                const float mean = mean_old[mt] + d1;
-                const float rstd = rsqrtf(fmaxf(var, 0.f) + eps);
-                const int m = mrow + 16 * mt;
-                if (m < M) {
-                    T* xo = xn_out + (size_t)m * E + col0;
-#pragma unroll
-                    for (int k6 = 0; k6 < NTH / 2; ++k6) {
-                        vec8 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            o[r] = (T)((acc[2 * k6][mt][r] - mean) * rstd);
-                            o[4 + r] = (T)((acc[2 * k6 + 1][mt][r] - mean) * rstd);
-                        }
-                        *reinterpret_cast<vec8*>(xo + 32 * k6) = o;
+                    for (int t = 0; t < NT; ++t) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
+                        ACC(t, 0) = __builtin_bit_cast(u32x4, bv);
+                        ACC(t, 1) = __builtin_bit_cast(u32x4, bv);
                     }
                 }
+                // ---- GEMM2 of chunk c
+                const vec8 hf0 = *reinterpret_cast<const vec8*>(hslot + (sc & 1) * 8192);
+                const vec8 hf1 = *reinterpret_cast<const vec8*>(hslot + 1024 + (sc & 1) * 8192);
+                const unsigned w2a = lds_base + W2_RING + (s % NSLOT) * W2_BYTES + frag_off;
+                vec8 w[NT];
+                wait_lgkm<0>();
+                static_for<0, DEPTH>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<q * 1024>(w[q], w2a); });
+                static_for<0, NT>([&](auto i) {
+                    constexpr int q = decltype(i)::value;
+                    if constexpr (q + DEPTH < NT) lds_read_b128<(q + DEPTH) * 1024>(w[q + DEPTH], w2a);
+                    wait_lgkm<(NT - 1 - q < DEPTH) ? (NT - 1 - q) : DEPTH>();
+                    ACC(q, 0) = __builtin_bit_cast(u32x4, mfma16(w[q], hf0, __builtin_bit_cast(f32x4, ACC(q, 0))));
+                    ACC(q, 1) = __builtin_bit_cast(u32x4, mfma16(w[q], hf1, __builtin_bit_cast(f32x4, ACC(q, 1))));
+                });
+                STAMP(t3);
+                ACCUM(2, t2, t3);                        // GEMM2
+                if (c == NCHUNK - 1) {
+                    // ---- epilogue of tile sc/48: residual (+ LayerScale), store x, next LayerNorm from registers
+                    const int tile = blockIdx.x + (sc / NCHUNK) * gridDim.x;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int m = tile * 128 + pr * 32 + 16 * mt + frow;
+                        float* xw = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
+#pragma unroll
+                        for (int kb = 0; kb < KS; kb += 4) {
+                            float4 xo[8];
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) xo[k2] = *reinterpret_cast<const float4*>(xw + 32 * (kb + (k2 >> 1)) + 4 * (k2 & 1));
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) {
+                                const int t = 2 * kb + k2;
+                                float4 gs = make_float4(1.f, 1.f, 1.f, 1.f);
+                                if (ls2) gs = *reinterpret_cast<const float4*>(ls2 + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
+                                f32x4 a = __builtin_bit_cast(f32x4, ACC(t, mt));
+                                a[0] = xo[k2].x + gs.x * a[0];
+                                a[1] = xo[k2].y + gs.y * a[1];
+                                a[2] = xo[k2].z + gs.z * a[2];
+                                a[3] = xo[k2].w + gs.w * a[3];
+                                ACC(t, mt) = __builtin_bit_cast(u32x4, a);
+                                if (m < M) *reinterpret_cast<float4*>(xw + 32 * (t >> 1) + 4 * (t & 1)) = make_float4(a[0], a[1], a[2], a[3]);
+                            }
+                        }
+                        if (xn_out) {
+                            float sum = 0.f;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const f32x4 a = __builtin_bit_cast(f32x4, ACC(t, mt));
+                                sum += a[0] + a[1] + a[2] + a[3];
+                            }
+                            sum += __shfl_xor(sum, 16, 64);
+                            sum += __shfl_xor(sum, 32, 64);
+                            const float mean = sum * (1.0f / E);
+                            float sq = 0.f;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const f32x4 a = __builtin_bit_cast(f32x4, ACC(t, mt));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { const float d = a[r] - mean; sq = fmaf(d, d, sq); }
+                            }
+                            sq += __shfl_xor(sq, 16, 64);
+                            sq += __shfl_xor(sq, 32, 64);
+                            const float rstd = rsqrtf(sq * (1.0f / E) + eps);
+                            if (m < M) {
+                                T* xo = xn_out + (size_t)m * E + 8 * g;
+#pragma unroll
+                                for (int ks = 0; ks < KS; ++ks) {
+                                    vec8 o;
+                                    const f32x4 a0 = __builtin_bit_cast(f32x4, ACC(2 * ks, mt));
+                                    const f32x4 a1 = __builtin_bit_cast(f32x4, ACC(2 * ks + 1, mt));
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        o[r] = (T)((a0[r] - mean) * rstd);
+                                        o[4 + r] = (T)((a1[r] - mean) * rstd);
+                                    }
+                                    *reinterpret_cast<vec8*>(xo + 32 * ks) = o;
+                                }
+                            }
+                        }
+                    }
+                }
+                STAMP(t4);
+                ACCUM(3, t3, t4);                        // epilogue (c == 47 only)
             }
-            asm volatile("s_barrier" ::: "memory");      // statistics consumed before the next tile's swaps
         }
+#ifdef MLP_STAMPS
+        if (lane == 0) for (int i = 0; i < 4; ++i) g_stamps[(blockIdx.x * 8 + wave) * 4 + i] = st[i];
+#endif
     }
 }
 
@@ -302,6 +349,12 @@ int launch_t(float* x, void* xn_out, const void* wpack, const float* b1f, const 
 }
 
 }  // namespace
+
+#ifdef MLP_STAMPS
+extern "C" int mst_debug_mlp_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, const float* ls2,
                  int64_t M, int E_, float eps, hipStream_t s) {
