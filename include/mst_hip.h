@@ -106,16 +106,17 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
 
 /* Fused MLP half of a ViT block (block.py:93-94,113; mlp.py:34-40), E = 384, 16-bit operands:
  *   x[M,E] (fp32, in place) += ls2 * (fc2(gelu(fc1(normalise(x)))) + b2);  xn_out (nullable, dtype) = normalise(x_new)
+ * with LayerScale ls2 folded by the caller into W2's rows and into b2f = ls2 * b2 (ls2 = 1 when absent).
  * normalise = LayerNorm without affine (eps).  The hidden activations stay on chip.
  * wpack: 48 chunks x 49152 B, chunk c = LDS image of W1f rows [32c,32c+32) and W2 columns [32c,32c+32):
  *   W1 part  [ks 0..11][h 0..31][slot 0..3][8]  = W1f[32c+h][32ks + 8(slot^f(h)) ..+7],   f(r) = (-(r>>2))&3
- *   W2 part  [R 0..383][slot 0..3][8]           = W2[n(R)][32c + phys(slot^f(R), 0..7)]
+ *   W2 part  [R 0..383][slot 0..3][8]           = ls2[n(R)] * W2[n(R)][32c + phys(slot^f(R), 0..7)]
  *     n(R)      = 32((R>>4)>>1) + 8((R&15)>>2) + 4((R>>4)&1) + (R&3)
  *     phys(c,j) = j<4 ? 4c+j : 16+4c+(j-4)
  *   W1f = fc1_w * ln2_w (columns);  b1f (fp32, 1536+32 padded) = fc1_b + fc1_w . ln2_b;  b2 = fc2 bias.
  * (new-vit_amd/mst/models/dino.py::_pack_mlp builds it.) */
-int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2,
-                  const float* ls2, int64_t M, int E, float eps, mst_stream_t stream);
+int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2f,
+                  int64_t M, int E, float eps, mst_stream_t stream);
 
 /* Whole per-slice encoder ------------------------------------------------------------------ */
 typedef struct mst_vit_layer {
@@ -130,9 +131,9 @@ typedef struct mst_vit_layer {
     /* Optional fused-LayerNorm form (16-bit modes, E = 384).  When mlp_pack != NULL for every layer the
      * encoder runs  normalise -> QKV(qkv_wf, qkv_bf) -> attention -> proj -> mst_mlp_fused  per block:
      *   qkv_wf = qkv_w * ln1_w (columns), qkv_bf = qkv_b + qkv_w . ln1_b            (norm1 folded)
-     *   mlp_pack / fc1_bf: see mst_mlp_fused                                          (norm2 folded) */
+     *   mlp_pack / fc1_bf / fc2_bf: see mst_mlp_fused                        (norm2 and ls2 folded) */
     const void* qkv_wf; const float* qkv_bf;
-    const void* mlp_pack; const float* fc1_bf;
+    const void* mlp_pack; const float* fc1_bf; const float* fc2_bf;
 } mst_vit_layer;
 
 typedef struct mst_vit_weights {

@@ -118,10 +118,10 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
                               (hipStream_t)stream);
 }
 
-int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2,
-                  const float* ls2, int64_t M, int E, float eps, mst_stream_t stream) {
-    MST_CHECK_ARG(x && wpack && b1f && b2, "mlp_fused: null pointer");
-    return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2, ls2, M, E, eps, (hipStream_t)stream);
+int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2f,
+                  int64_t M, int E, float eps, mst_stream_t stream) {
+    MST_CHECK_ARG(x && wpack && b1f && b2f, "mlp_fused: null pointer");
+    return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2f, M, E, eps, (hipStream_t)stream);
 }
 
 // ---- per-slice encoder ----------------------------------------------------------------------
@@ -199,7 +199,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         // fused-LayerNorm pipeline (16-bit, E = 384): norm1 folded into QKV, norm2 + MLP in one kernel
         bool fused = (dt != MST_F32) && E == 384;
         for (int l = 0; l < w->depth && fused; ++l)
-            fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
+            fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
         if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
         for (int l = 0; l < w->depth; ++l) {
             const mst_vit_layer* L = &w->layers[l];
@@ -219,7 +219,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
             // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
             if (fused) {
-                RUNK(MST_K_MLP_FUSED, launch_mlp16(x, (l + 1 < w->depth) ? xn : nullptr, dt, L->mlp_pack, L->fc1_bf, L->fc2_b, L->ls2, Mc, E, 1e-6f, s));
+                RUNK(MST_K_MLP_FUSED, launch_mlp16(x, (l + 1 < w->depth) ? xn : nullptr, dt, L->mlp_pack, L->fc1_bf, L->fc2_bf, Mc, E, 1e-6f, s));
             } else {
                 RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
                 RUNK(MST_K_GEMM_FC1, mst_gemm(xn, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));

@@ -129,8 +129,8 @@ int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
-int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, const float* ls2,
-                 int64_t M, int E, float eps, hipStream_t s);
+int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, int64_t M, int E,
+                 float eps, hipStream_t s);
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s);
 int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
 int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,

@@ -31,7 +31,7 @@ _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
-                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf")]
+                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf")]
 
 
 class VitWeights(C.Structure):
@@ -59,7 +59,7 @@ SIGNATURES = {
     "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
-    "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
     "mst_vit_encode": (_i, [C.POINTER(VitWeights), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -192,22 +192,27 @@ def patch_embed(vol: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, prefix:
     return x
 
 
-def mlp_fused(x: torch.Tensor, wpack: torch.Tensor, b1f: torch.Tensor, b2: torch.Tensor, ls2: Optional[torch.Tensor],
+def mlp_fused(x: torch.Tensor, wpack: torch.Tensor, b1f: torch.Tensor, b2f: torch.Tensor,
               xn_out: Optional[torch.Tensor], dtype: torch.dtype, eps: float = 1e-6):
-    """x [M,384] fp32 updated in place; xn_out (optional, `dtype`) receives normalise(x_new)."""
+    """x [M,384] fp32 updated in place; xn_out (optional, `dtype`) receives normalise(x_new).
+    wpack / b1f / b2f from pack_mlp (LayerNorm affine and LayerScale folded)."""
     _dev(x, "mlp_fused")
     M, E = x.shape
-    _check(load().mst_mlp_fused(ptr(x), ptr(xn_out), _DT[dtype], ptr(wpack), ptr(b1f), ptr(b2), ptr(ls2), M, E, eps,
+    _check(load().mst_mlp_fused(ptr(x), ptr(xn_out), _DT[dtype], ptr(wpack), ptr(b1f), ptr(b2f), M, E, eps,
                                 stream_of(x)), "mst_mlp_fused")
 
 
-def pack_mlp(fc1_w, fc1_b, fc2_w, ln_w, ln_b, dtype: torch.dtype):
+def pack_mlp(fc1_w, fc1_b, fc2_w, fc2_b, ln_w, ln_b, ls2, dtype: torch.dtype):
     """Host-side packing of one MLP for mst_mlp_fused (layout: include/mst_hip.h).  Inputs fp32 tensors on any
-    device: fc1_w [1536,384], fc1_b [1536], fc2_w [384,1536], ln_w/ln_b [384].  Returns (wpack [48,24576] dtype,
-    b1f [1568] fp32)."""
+    device: fc1_w [1536,384], fc1_b [1536], fc2_w [384,1536], fc2_b [384], ln_w/ln_b [384], ls2 [384] or None.
+    Returns (wpack [48,24576] dtype, b1f [1568] fp32, b2f [384] fp32)."""
     dev = fc1_w.device
     w1f = fc1_w.float() * ln_w.float()[None, :]
     b1f = fc1_b.float() + fc1_w.float() @ ln_b.float()
+    b2f = fc2_b.float().clone()
+    if ls2 is not None:                                   # LayerScale folded into fc2 (layer_scale.py:26-27)
+        fc2_w = fc2_w.float() * ls2.float()[:, None]
+        b2f = b2f * ls2.float()
     ar = lambda n: torch.arange(n, device=dev)
     # W1 image: [chunk][ks][h][slot][8]
     w1c = w1f.view(48, 32, 12, 4, 8).permute(0, 2, 1, 3, 4)                    # [chunk, ks, h, c, j]
@@ -227,7 +232,7 @@ def pack_mlp(fc1_w, fc1_b, fc2_w, ln_w, ln_b, dtype: torch.dtype):
     wpack = torch.cat([w1img.reshape(48, -1), w2img.reshape(48, -1)], dim=1).to(dtype).contiguous()
     b1p = torch.zeros(1536 + 32, device=dev, dtype=torch.float32)
     b1p[:1536] = b1f
-    return wpack, b1p
+    return wpack, b1p, b2f.contiguous()
 
 
 def vit_workspace_bytes(w: VitWeights, H: int, W: int, chunk: int) -> int:

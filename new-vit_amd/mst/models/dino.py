@@ -329,11 +329,12 @@ class DinoV2ClassifierSlice(BasicClassifier):
                     wq = b.attn.qkv.weight.detach().to(dev, torch.float32)
                     L.qkv_wf = hip.ptr(cmp(wq * g1[None, :]))
                     L.qkv_bf = hip.ptr(f32(b.attn.qkv.bias.detach().to(dev, torch.float32) + wq @ be1))
-                    wpack, b1p = hip.pack_mlp(b.mlp.fc1.weight.detach().to(dev), b.mlp.fc1.bias.detach().to(dev),
-                                              b.mlp.fc2.weight.detach().to(dev), b.norm2.weight.detach().to(dev),
-                                              b.norm2.bias.detach().to(dev), tdt)
-                    keep.extend([wpack, b1p])
-                    L.mlp_pack, L.fc1_bf = hip.ptr(wpack), hip.ptr(b1p)
+                    ls = b.ls2.gamma.detach().to(dev) if hasattr(b, "ls2") else None
+                    wpack, b1p, b2p = hip.pack_mlp(b.mlp.fc1.weight.detach().to(dev), b.mlp.fc1.bias.detach().to(dev),
+                                                   b.mlp.fc2.weight.detach().to(dev), b.mlp.fc2.bias.detach().to(dev),
+                                                   b.norm2.weight.detach().to(dev), b.norm2.bias.detach().to(dev), ls, tdt)
+                    keep.extend([wpack, b1p, b2p])
+                    L.mlp_pack, L.fc1_bf, L.fc2_bf = hip.ptr(wpack), hip.ptr(b1p), hip.ptr(b2p)
         vit = hip.VitWeights()
         vit.embed_dim, vit.depth, vit.num_heads, vit.num_registers = E, enc.depth, enc.num_heads, R
         vit.compute_dtype = cdt

@@ -182,10 +182,11 @@ def test_mlp_fused(hip, dt, M, with_ls, with_xn):
     w2, b2 = rnd((E, Hd), 53) / math.sqrt(Hd), rnd((E,), 54) * 0.1
     g, be = rnd((E,), 55) * 0.2 + 1, rnd((E,), 56) * 0.2
     ls = (rnd((E,), 57) * 0.3 + 1) if with_ls else None
-    wpack, b1p = hip.pack_mlp(w1.cuda(), b1.cuda(), w2.cuda(), g.cuda(), be.cuda(), tdt)
+    wpack, b1p, b2p = hip.pack_mlp(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), g.cuda(), be.cuda(),
+                                   None if ls is None else ls.cuda(), tdt)
     xc = x.cuda().clone()
     xn = torch.empty(M, E, dtype=tdt, device="cuda") if with_xn else None
-    hip.mlp_fused(xc, wpack, b1p, b2.cuda(), None if ls is None else ls.cuda(), xn, tdt)
+    hip.mlp_fused(xc, wpack, b1p, b2p, xn, tdt)
     xd = x.double()
     h = torch.nn.functional.layer_norm(xd, (E,), g.double(), be.double(), 1e-6)
     h = h @ w1.double().t() + b1.double()

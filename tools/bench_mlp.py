@@ -14,16 +14,16 @@ x = torch.randn(M, E, device="cuda")
 w1 = torch.randn(H, E, device="cuda") / E ** 0.5; b1 = torch.randn(H, device="cuda") * 0.1
 w2 = torch.randn(E, H, device="cuda") / H ** 0.5; b2 = torch.randn(E, device="cuda") * 0.1
 g = torch.ones(E, device="cuda"); be = torch.zeros(E, device="cuda")
-wpack, b1p = hip.pack_mlp(w1, b1, w2, g, be, dt)
+wpack, b1p, b2p = hip.pack_mlp(w1, b1, w2, b2, g, be, None, dt)
 xn = torch.empty(M, E, device="cuda", dtype=dt)
 for _ in range(2):
-    hip.mlp_fused(x, wpack, b1p, b2, None, xn, dt)
+    hip.mlp_fused(x, wpack, b1p, b2p, xn, dt)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 reps = 10
 for _ in range(reps):
-    hip.mlp_fused(x, wpack, b1p, b2, None, xn, dt)
+    hip.mlp_fused(x, wpack, b1p, b2p, xn, dt)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps

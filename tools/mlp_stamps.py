@@ -8,11 +8,11 @@ import torch
 from mst import hip
 M = 350720; dt = torch.bfloat16; E, H = 384, 1536
 x = torch.randn(M, E, device="cuda")
-wpack, b1p = hip.pack_mlp(torch.randn(H, E, device="cuda") / E ** .5, torch.randn(H, device="cuda") * .1,
-                          torch.randn(E, H, device="cuda") / H ** .5, torch.ones(E, device="cuda"), torch.zeros(E, device="cuda"), dt)
 b2 = torch.zeros(E, device="cuda"); xn = torch.empty(M, E, device="cuda", dtype=dt)
+wpack, b1p, b2p = hip.pack_mlp(torch.randn(H, E, device="cuda") / E ** .5, torch.randn(H, device="cuda") * .1,
+                               torch.randn(E, H, device="cuda") / H ** .5, b2, torch.ones(E, device="cuda"), torch.zeros(E, device="cuda"), None, dt)
 for _ in range(3):
-    hip.mlp_fused(x, wpack, b1p, b2, None, xn, dt)
+    hip.mlp_fused(x, wpack, b1p, b2p, xn, dt)
 torch.cuda.synchronize()
 lib = hip.load()
 buf = (C.c_ulonglong * (256 * 8 * 4))()
