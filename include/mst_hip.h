@@ -201,6 +201,13 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
                           int heads, int N, int num_registers, int sheads, float* plane,
                           float* slice_attn, float* maps, mst_stream_t stream);
 
+/* Attention rollout (dino.py:204-212, get_attention_cls): R = maps[L-1]; for l = L-2 .. 0: R = maps[l] @ R,
+ * every map fp32 [batch, N, N] row-major (batch = n*heads), exact fp32 MFMA.  `maps` is a HOST array of
+ * n_layers device pointers.  The product lands in `out`; `tmp` (same size as out) is scratch and may be NULL
+ * when n_layers <= 2.  Neither may alias a map.  n_layers == 1 copies the map. */
+int mst_attention_rollout(const float* const* maps, int n_layers, int64_t batch, int N, float* out,
+                          float* tmp, mst_stream_t stream);
+
 /* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only; off by
  * default).  When enabled, every launch is bracketed by hipEventRecord on the call's own stream;
  * mst_profile_collect waits for the recorded events, returns the accumulated milliseconds and

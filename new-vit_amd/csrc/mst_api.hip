@@ -324,6 +324,32 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
                           (hipStream_t)stream);
 }
 
+int mst_attention_rollout(const float* const* maps, int n_layers, int64_t batch, int N, float* out, float* tmp,
+                          mst_stream_t stream) {
+    MST_CHECK_ARG(maps && out && n_layers >= 1 && batch > 0 && N > 0, "rollout: bad arguments");
+    MST_CHECK_ARG(n_layers <= 2 || tmp, "rollout: tmp is required for more than two maps");
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < n_layers; ++l)
+        MST_CHECK_ARG(maps[l] && maps[l] != out && maps[l] != tmp, "rollout: map %d is null or aliases out/tmp", l);
+    if (n_layers == 1) {
+        if (hipMemcpyAsync(out, maps[0], sizeof(float) * (size_t)batch * N * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            mst_set_error("rollout: copy failed");
+            return MST_ELAUNCH;
+        }
+        return MST_OK;
+    }
+    // n_layers - 1 products, alternating tmp/out so that the last one lands in `out`
+    const float* cur = maps[n_layers - 1];
+    const int links = n_layers - 1;
+    for (int i = 0; i < links; ++i) {
+        float* dst = ((links - 1 - i) & 1) ? tmp : out;
+        int rc = launch_bmm32_nn(maps[n_layers - 2 - i], cur, dst, batch, N, N, N, s);
+        if (rc != MST_OK) return rc;
+        cur = dst;
+    }
+    return MST_OK;
+}
+
 int mst_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

@@ -148,6 +148,7 @@ int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const u
                       const float* rope, float* out, float* probs, hipStream_t s);
 int launch_rows_copy(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int rows,
                      int cols, hipStream_t s);
+int launch_bmm32_nn(const float* A, const float* B, float* C, int64_t batch, int M, int N, int K, hipStream_t s);
 int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
 int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,
                    int R, int sheads, float* plane, float* slice_attn, float* maps, hipStream_t s);

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Optional
+from typing import Sequence, Optional
 
 import torch
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "mst_fusion_workspace_bytes": (_sz, [C.POINTER(FusionWeights), _i, _i]),
     "mst_slice_fusion": (_i, [C.POINTER(FusionWeights), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mst_attention_readout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mst_attention_rollout": (_i, [C.POINTER(_vp), _i, _i64, _i, _vp, _vp, _vp]),
     "mst_profile_enable": (_i, [_i]),
     "mst_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
@@ -266,6 +267,23 @@ def attention_readout(cls_probs_last: Optional[torch.Tensor], slice_probs: Optio
     t = cls_probs_last if cls_probs_last is not None else slice_probs
     _check(load().mst_attention_readout(ptr(cls_probs_last), ptr(slice_probs), B, D, heads, N, num_registers, sheads,
                                         ptr(plane), ptr(slice_attn), ptr(maps), stream_of(t)), "mst_attention_readout")
+
+
+def attention_rollout(maps: Sequence[torch.Tensor]) -> torch.Tensor:
+    """get_attention_cls (dino.py:204-212): maps[0] @ maps[1] @ ... @ maps[-1] on full fp32 [..., N, N] maps."""
+    m0 = maps[0]
+    _dev(m0, "attention_rollout")
+    N = m0.shape[-1]
+    for m in maps:
+        if m.dtype != torch.float32 or tuple(m.shape) != tuple(m0.shape) or m.shape[-2] != N or not m.is_contiguous():
+            raise ValueError("attention_rollout: maps must be contiguous fp32 [..., N, N] tensors of one shape")
+    batch = m0.numel() // (N * N)
+    out = torch.empty_like(m0)
+    tmp = torch.empty_like(m0) if len(maps) > 2 else None
+    arr = (_vp * len(maps))(*[ptr(m) for m in maps])
+    _check(load().mst_attention_rollout(arr, len(maps), batch, N, ptr(out), ptr(tmp), stream_of(m0)),
+           "mst_attention_rollout")
+    return out
 
 
 def profile_enable(on: bool):

@@ -535,7 +535,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         if not self.attention_maps or self.attention_maps[-1].shape[-2] != self.attention_maps[-1].shape[-1]:
             raise RuntimeError("get_attention_cls needs the full [n,h,N,N] maps: construct the model with "
                                "full_attention_maps=True and run forward(save_attn=True)")
-        raise NotImplementedError("attention rollout over full maps is not on the HIP path yet")
+        return hip.attention_rollout([m.contiguous() for m in self.attention_maps])   # [B*D, heads, N, N]
 
 
 class DinoV3ClassifierSlice(BasicClassifier):

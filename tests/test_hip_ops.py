@@ -334,3 +334,18 @@ def test_attention_readout(hip):
     assert rel_l2(sa.cpu(), O.slice_attention(sp).reshape(-1)) < 1e-6
     assert rel_l2(maps.cpu(), O.attention_maps(cls[:, :, None, :], sp)) < 1e-6
     assert torch.allclose(plane.sum(-1).cpu(), torch.ones(B * D, heads), atol=1e-5)
+
+
+@pytest.mark.parametrize("N,batch,layers", [(17, 5, 1), (37, 18, 2), (130, 7, 3), (257, 12, 12), (1370, 2, 3)])
+def test_attention_rollout_chain(hip, N, batch, layers):
+    """Batched exact-fp32 chain A_0 @ ... @ A_last on row-stochastic maps, ragged N, vs an fp64 product."""
+    from oracle import mst_oracle as O
+    g = torch.Generator().manual_seed(N + layers)
+    maps = [torch.rand(batch, N, N, generator=g).mul(4).softmax(-1) for _ in range(layers)]
+    out = hip.attention_rollout([m.cuda() for m in maps])
+    ref = O.attention_rollout([m.double() for m in maps])
+    assert out.shape == (batch, N, N)
+    assert rel_l2(out.cpu().double(), ref) < 2e-6
+    assert torch.allclose(out.sum(-1).cpu(), torch.ones(batch, N), atol=1e-4)   # products of stochastic maps stay stochastic
+    with pytest.raises(ValueError):
+        hip.attention_rollout([maps[0].cuda(), maps[0][:, :, :-1].cuda()])

@@ -163,3 +163,27 @@ def test_hub_layout_layerscale_registers_against_oracle():
     assert np.abs(logits.cpu().numpy() - ref["logits"].numpy()).max() < 1e-4
     assert rel_l2(model.get_plane_attention().cpu(), O.plane_attention(ref["vit_maps"][-1], 4)) < 1e-3
     assert rel_l2(model.get_attention_maps().cpu(), O.attention_maps(ref["vit_maps"][-1], ref["slice_map"], 4)) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+def test_attention_rollout_matches_reference_fixture(mode):
+    """get_attention_cls (dino.py:204-212): full [n,h,N,N] maps of all 12 layers, chained on the device."""
+    g = load_golden("rollout_1x3x84")
+    model = build({}, int(g["seed"]), mode, full_attention_maps=True)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    with torch.no_grad():
+        logits = model(src, save_attn=True)
+        roll = model.get_attention_cls()
+    tl, _, tm = TOL[mode]
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
+    assert len(model.attention_maps) == 12 and tuple(model.attention_maps[0].shape) == g["vit_full_first"].shape
+    assert rel_l2(model.attention_maps[0].cpu(), g["vit_full_first"]) < tm
+    assert rel_l2(model.attention_maps[-1].cpu(), g["vit_full_last"]) < tm
+    assert tuple(roll.shape) == g["attention_cls"].shape
+    assert rel_l2(roll.cpu(), g["attention_cls"]) < tm
+    # without the full maps the rollout must refuse, not approximate
+    plain = build({}, int(g["seed"]), mode)
+    with torch.no_grad():
+        plain(src, save_attn=True)
+    with pytest.raises(RuntimeError):
+        plain.get_attention_cls()

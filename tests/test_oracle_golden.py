@@ -130,3 +130,18 @@ def test_error_fixture_messages():
     with pytest.raises(AssertionError) as e:
         O.vit_encode(sd, torch.zeros(2, 224, 230))
     assert str(e.value) == ref["224x230"]["message"]
+
+
+def test_attention_rollout_matches_reference():
+    """get_attention_cls (dino.py:204-212) on the reference's stored full maps."""
+    g = load_golden("rollout_1x3x84")
+    sd = synth.synth_state_dict("s", int(g["seed"]))
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    with torch.no_grad():
+        out = O.forward(sd, src, keep="full")
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() < 2e-5
+    assert np.abs(out["vit_maps"][0].numpy() - g["vit_full_first"]).max() < 5e-6
+    assert np.abs(out["vit_maps"][-1].numpy() - g["vit_full_last"]).max() < 5e-6
+    roll = O.attention_rollout(out["vit_maps"])
+    assert roll.shape == g["attention_cls"].shape
+    assert rel_l2(roll, g["attention_cls"]) < 1e-5

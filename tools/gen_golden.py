@@ -258,6 +258,20 @@ def case_errors(dino, synth):
     print(res)
 
 
+@torch.no_grad()
+def case_rollout(dino, synth, name, shape, seed):
+    """get_attention_cls (dino.py:204-212) on the reference's own stored full maps."""
+    model, sd = build(dino, synth, seed)
+    src = synth.synth_volume(shape, seed + 100)
+    out = {"seed": seed, "shape": np.array(shape)}
+    out["logits"] = np_(model(src, save_attn=True))
+    out["vit_full_first"] = np_(model.attention_maps[0])
+    out["vit_full_last"] = np_(model.attention_maps[-1])
+    out["attention_cls"] = np_(model.get_attention_cls())
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -285,6 +299,7 @@ def main():
                                             plane_subset=[0, 31, 63]),
         "s504_1x4x504": lambda: case_end2end(dino, synth, "s504_1x4x504", (1, 1, 4, 504, 504), 7, chunk=4,
                                              plane_subset=[0, 3]),
+        "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
     }
     for name, fn in cases.items():
         if args.only and name not in args.only:
