@@ -181,6 +181,7 @@ typedef struct mst_fusion_weights {
     const float* norm_w; const float* norm_b;             /* dino.py:95 */
     const float* rope_freqs;                              /* [head_dim/2] or NULL (RoPE) */
     const float* head_w; const float* head_b;             /* [out_ch, emb*] (dino.py:103) */
+    const float* liere_rot;                               /* [head_dim, head_dim] from mst_liere_rotation, or NULL (LieRE) */
 } mst_fusion_weights;
 
 /* dino.py:134-166 after the encoder: bottleneck, slice position embedding, CLS concat,
@@ -200,6 +201,13 @@ int mst_slice_fusion(const mst_fusion_weights* w, const float* emb, int B, int D
 int mst_attention_readout(const float* cls_probs_last, const float* slice_probs, int B, int D,
                           int heads, int N, int num_registers, int sheads, float* plane,
                           float* slice_attn, float* maps, mst_stream_t stream);
+
+/* LieRE rotation of the slice transformer (AttentionLiereRotator, rotary_embedding_torch.py:319-372;
+ * transformer_blocks.py:350-357): vars fp32 [n_blocks, block(block-1)/2, axes_length] (the module's ParameterList
+ * stacked; spacial_dims = 1) -> R fp32 [n_blocks*block, n_blocks*block], block-diagonal, R_blk = exp(A_blk) with the
+ * skew generator A_blk[i][j] = sum_p p * vars[blk][tril(i,j)][p].  block <= 16.  Weight preparation: call once per
+ * weight version and pass R as mst_fusion_weights.liere_rot. */
+int mst_liere_rotation(const float* vars, int n_blocks, int block, int axes_length, float* R, mst_stream_t stream);
 
 /* Attention rollout (dino.py:204-212, get_attention_cls): R = maps[L-1]; for l = L-2 .. 0: R = maps[l] @ R,
  * every map fp32 [batch, N, N] row-major (batch = n*heads), exact fp32 MFMA.  `maps` is a HOST array of

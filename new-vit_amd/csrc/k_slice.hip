@@ -30,6 +30,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void slice_attn_kernel(const float* __restrict__ qkv, int L, int heads,
                                                          const uint8_t* __restrict__ mask,
                                                          const float* __restrict__ rope,
+                                                         const float* __restrict__ liere,
                                                          float* __restrict__ out, float* __restrict__ probs) {
     extern __shared__ float sm[];
     float* Ks = sm;                 // [L][HD]
@@ -38,6 +39,22 @@ __global__ __launch_bounds__(256) void slice_attn_kernel(const float* __restrict
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     const int E = heads * HD, ld = 3 * E;
     const float* base = qkv + (int64_t)b * L * ld;
+    if (liere) {
+        // LieRE as the reference runs it (rotary_embedding_torch.py:347-396 + the view at transformer_blocks.py:
+        // 263-264): every q/k vector is multiplied by one rotation R [HD,HD]; the rotated tensor stays in
+        // [L, heads, HD] order and is then viewed as [heads, L, HD], so pseudo-head h, position j holds the
+        // vector of (token, head) pair number r = h*L + j of that order.  V keeps its own head.
+        for (int i = tid; i < L * HD; i += 256) {
+            const int j = i / HD, d = i % HD;
+            const int r = h * L + j, t = r / heads, hh = r % heads;
+            const float* kp = base + (int64_t)t * ld + E + hh * HD;
+            float a = 0.f;
+#pragma unroll 8
+            for (int e = 0; e < HD; ++e) a = fmaf(liere[d * HD + e], kp[e], a);
+            Ks[i] = a;
+            Vs[i] = base[(int64_t)j * ld + 2 * E + h * HD + d];
+        }
+    } else
     for (int i = tid; i < L * (HD / 2); i += 256) {
         const int j = i / (HD / 2), p = i % (HD / 2);
         const float* kp = base + (int64_t)j * ld + E + h * HD + 2 * p;
@@ -63,6 +80,16 @@ __global__ __launch_bounds__(256) void slice_attn_kernel(const float* __restrict
     for (int qi = tid; qi < L; qi += 256) {
         float q[HD];
         const float* qp = base + (int64_t)qi * ld + h * HD;
+        if (liere) {
+            const int r = h * L + qi;
+            qp = base + (int64_t)(r / heads) * ld + (r % heads) * HD;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                float a = 0.f;
+                for (int e = 0; e < HD; ++e) a = fmaf(liere[d * HD + e], qp[e], a);
+                q[d] = a * scale;
+            }
+        } else
 #pragma unroll
         for (int p = 0; p < HD / 2; ++p) {
             float q0 = qp[2 * p], q1 = qp[2 * p + 1];
@@ -110,6 +137,62 @@ __global__ __launch_bounds__(256) void slice_attn_kernel(const float* __restrict
             }
         }
     }
+}
+
+// R_blk = exp(A), A[i][j] = -A[j][i] = sum_p p * v[(i(i-1)/2 + j) * P + p] for i > j (flat_to_skew + the
+// position-index contraction of rotary_embedding_torch.py:319-326,364-366), written into the block diagonal
+// of R [hd, hd].  One workgroup of n*n threads per block; fp64 scaling-and-squaring with a degree-18 Taylor
+// polynomial at ||A/2^s||_1 <= 0.5 (truncation < 1e-21), so R is orthogonal to ~1e-13 before the fp32 store.
+__global__ void liere_expm_kernel(const float* __restrict__ vars, int n, int P, int hd, float* __restrict__ R) {
+    __shared__ double A[16 * 16], T[16 * 16], X[16 * 16], red[16];
+    __shared__ int sq;
+    const int blk = blockIdx.x, tid = threadIdx.x, i = tid / n, j = tid % n;
+    const float* v = vars + (int64_t)blk * (n * (n - 1) / 2) * P;
+    double a = 0.0;
+    if (i != j) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        const float* row = v + (int64_t)(hi * (hi - 1) / 2 + lo) * P;
+        for (int p = 0; p < P; ++p) a += (double)row[p] * (double)p;
+        if (i < j) a = -a;
+    }
+    A[tid] = a;
+    __syncthreads();
+    if (tid < n) {  // 1-norm: max column sum
+        double c = 0.0;
+        for (int r = 0; r < n; ++r) c += fabs(A[r * n + tid]);
+        red[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double nm = 0.0;
+        for (int c = 0; c < n; ++c) nm = fmax(nm, red[c]);
+        int s = 0;
+        while (nm > 0.5 && s < 60) { nm *= 0.5; ++s; }
+        sq = s;
+    }
+    __syncthreads();
+    const int s = sq;
+    a = ldexp(a, -s);
+    A[tid] = a;
+    // Horner: T = I + A/1 (I + A/2 (I + ... (I + A/18)))
+    T[tid] = (i == j ? 1.0 : 0.0) + a / 18.0;
+    __syncthreads();
+    for (int k = 17; k >= 1; --k) {
+        double acc = 0.0;
+        for (int e = 0; e < n; ++e) acc += A[i * n + e] * T[e * n + j];
+        X[tid] = (i == j ? 1.0 : 0.0) + acc / (double)k;
+        __syncthreads();
+        T[tid] = X[tid];
+        __syncthreads();
+    }
+    for (int q = 0; q < s; ++q) {
+        double acc = 0.0;
+        for (int e = 0; e < n; ++e) acc += T[i * n + e] * T[e * n + j];
+        __syncthreads();
+        T[tid] = acc;
+        __syncthreads();
+    }
+    R[(int64_t)(blk * n + i) * hd + blk * n + j] = (float)T[tid];
 }
 
 __global__ void rows_copy_kernel(const float* __restrict__ src, int64_t ss, float* __restrict__ dst, int64_t ds,
@@ -183,7 +266,7 @@ int launch_slice_tokens(const float* emb, const float* cls, const float* pos, in
 }
 
 int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const uint8_t* mask, const float* rope,
-                      float* out, float* probs, hipStream_t s) {
+                      const float* liere, float* out, float* probs, hipStream_t s) {
     const size_t sh = ((size_t)2 * L * hd + L) * sizeof(float);
     MST_CHECK_ARG(sh <= 160 * 1024, "slice_attn: L=%d head_dim=%d does not fit LDS", L, hd);
     const dim3 grid(B, heads), block(256);
@@ -191,7 +274,7 @@ int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const u
     case HD: {                                                                                                   \
         auto kern = slice_attn_kernel<HD>;                                                                       \
         if (sh > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        kern<<<grid, block, sh, s>>>(qkv, L, heads, mask, rope, out, probs);                                     \
+        kern<<<grid, block, sh, s>>>(qkv, L, heads, mask, rope, liere, out, probs);                                     \
         break;                                                                                                   \
     }
     switch (hd) {
@@ -200,6 +283,17 @@ int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const u
     }
 #undef SA_CASE
     return mst_check_launch("slice_attn");
+}
+
+int launch_liere_rotation(const float* vars, int n_blocks, int n, int P, float* R, hipStream_t s) {
+    MST_CHECK_ARG(n >= 2 && n <= 16 && n_blocks >= 1 && P >= 1, "liere_rotation: block size %d (2..16), %d blocks", n, n_blocks);
+    const int hd = n * n_blocks;
+    if (hipMemsetAsync(R, 0, sizeof(float) * hd * hd, s) != hipSuccess) {
+        mst_set_error("liere_rotation: memset failed");
+        return MST_ELAUNCH;
+    }
+    liere_expm_kernel<<<dim3(n_blocks), dim3(n * n), 0, s>>>(vars, n, P, hd, R);
+    return mst_check_launch("liere_expm");
 }
 
 int launch_rows_copy(const float* src, int64_t ss, float* dst, int64_t ds, int rows, int cols, hipStream_t s) {

@@ -290,7 +290,17 @@ int mst_slice_fusion(const mst_fusion_weights* w, const float* emb, int B, int D
         // x = x + out_proj(attn(in_proj(norm1 x)))                 transformer_blocks.py:567,576-582
         RUN(launch_layernorm(xs, e, w->ln1_w, w->ln1_b, y, MST_F32, e, ML, e, 1e-5f, s));
         RUN(launch_gemm32(y, e, w->in_proj_w, e, w->in_proj_b, qkv, 3 * e, ML, 3 * e, e, MST_EPI_BIAS, nullptr, 1.f, 0, s));
-        RUN(launch_slice_attn(qkv, B, L, w->num_heads, hd, key_padding_mask, w->rope_freqs, ao, slice_probs, s));
+        if (w->liere_rot) {
+            // the reference's LieRE path views [B, 33, heads, hd] and then [B*heads, L, hd] of a permuted tensor:
+            // both views fail (RuntimeError) unless D == 32 and B == 1 (rotary_embedding_torch.py:349;
+            // transformer_blocks.py:263)
+            MST_CHECK_ARG(!w->rope_freqs, "slice_fusion: rope_freqs and liere_rot are exclusive");
+            MST_CHECK_ARG(L == 33, "slice_fusion: LieRE is built for 33 tokens (axes_length, transformer_blocks.py:355): "
+                          "shape '[%d, 33, %d, %d]' is invalid for %d slices", B, w->num_heads, hd, D);
+            MST_CHECK_ARG(B == 1, "slice_fusion: LieRE: view size is not compatible with the rotated tensor's "
+                          "size and stride for batch %d > 1 (transformer_blocks.py:263)", B);
+        }
+        RUN(launch_slice_attn(qkv, B, L, w->num_heads, hd, key_padding_mask, w->rope_freqs, w->liere_rot, ao, slice_probs, s));
         RUN(launch_gemm32(ao, e, w->out_proj_w, e, w->out_proj_b, xs, e, ML, e, e, MST_EPI_RESIDUAL, nullptr, 1.f, 0, s));
         // x = x + linear2(relu(linear1(norm2 x)))                  transformer_blocks.py:568,585-587
         RUN(launch_layernorm(xs, e, w->ln2_w, w->ln2_b, y, MST_F32, e, ML, e, 1e-5f, s));
@@ -322,6 +332,11 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
     MST_CHECK_ARG(B > 0 && D > 0 && heads > 0 && N > 1 + num_registers, "readout: bad sizes");
     return launch_readout(cls_probs_last, slice_probs, B, D, heads, N, num_registers, sheads, plane, slice_attn, maps,
                           (hipStream_t)stream);
+}
+
+int mst_liere_rotation(const float* vars, int n_blocks, int block, int axes_length, float* R, mst_stream_t stream) {
+    MST_CHECK_ARG(vars && R, "liere_rotation: null pointer");
+    return launch_liere_rotation(vars, n_blocks, block, axes_length, R, (hipStream_t)stream);
 }
 
 int mst_attention_rollout(const float* const* maps, int n_layers, int64_t batch, int N, float* out, float* tmp,

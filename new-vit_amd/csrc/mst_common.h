@@ -145,7 +145,8 @@ int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double off
 int launch_slice_tokens(const float* emb, const float* cls, const float* pos, int B, int D, int E,
                         float* xs, hipStream_t s);
 int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const uint8_t* mask,
-                      const float* rope, float* out, float* probs, hipStream_t s);
+                      const float* rope, const float* liere, float* out, float* probs, hipStream_t s);
+int launch_liere_rotation(const float* vars, int n_blocks, int n, int P, float* R, hipStream_t s);
 int launch_rows_copy(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int rows,
                      int cols, hipStream_t s);
 int launch_bmm32_nn(const float* A, const float* B, float* C, int64_t batch, int M, int N, int K, hipStream_t s);

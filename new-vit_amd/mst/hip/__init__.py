@@ -46,7 +46,7 @@ class FusionWeights(C.Structure):
                [(n, _vp) for n in ("bottleneck_w", "bottleneck_b", "slice_pos_emb", "cls_token",
                                    "ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
                                    "ln2_w", "ln2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
-                                   "norm_w", "norm_b", "rope_freqs", "head_w", "head_b")]
+                                   "norm_w", "norm_b", "rope_freqs", "head_w", "head_b", "liere_rot")]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/mst_hip.h is exported
@@ -66,6 +66,7 @@ SIGNATURES = {
     "mst_fusion_workspace_bytes": (_sz, [C.POINTER(FusionWeights), _i, _i]),
     "mst_slice_fusion": (_i, [C.POINTER(FusionWeights), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mst_attention_readout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mst_liere_rotation": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_attention_rollout": (_i, [C.POINTER(_vp), _i, _i64, _i, _vp, _vp, _vp]),
     "mst_profile_enable": (_i, [_i]),
     "mst_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -267,6 +268,19 @@ def attention_readout(cls_probs_last: Optional[torch.Tensor], slice_probs: Optio
     t = cls_probs_last if cls_probs_last is not None else slice_probs
     _check(load().mst_attention_readout(ptr(cls_probs_last), ptr(slice_probs), B, D, heads, N, num_registers, sheads,
                                         ptr(plane), ptr(slice_attn), ptr(maps), stream_of(t)), "mst_attention_readout")
+
+
+def liere_rotation(vars_: Sequence[torch.Tensor]) -> torch.Tensor:
+    """AttentionLiereRotator's rotation R [hd, hd] from its ParameterList (each [n(n-1)/2, axes_length, 1])."""
+    v = torch.stack([t.detach().float().reshape(t.shape[0], t.shape[1]) for t in vars_]).contiguous()
+    _dev(v, "liere_rotation")
+    nb, m, P = v.shape
+    n = int(round((1 + (1 + 8 * m) ** 0.5) / 2))
+    if n * (n - 1) // 2 != m:
+        raise ValueError(f"liere_rotation: {m} parameters per block is not n(n-1)/2")
+    R = torch.empty((nb * n, nb * n), dtype=torch.float32, device=v.device)
+    _check(load().mst_liere_rotation(ptr(v), nb, n, P, ptr(R), stream_of(v)), "mst_liere_rotation")
+    return R
 
 
 def attention_rollout(maps: Sequence[torch.Tensor]) -> torch.Tensor:

@@ -155,9 +155,13 @@ class _SelfAttn(_Params):
             holder.freqs = nn.Parameter(1.0 / (256 ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd)),
                                         requires_grad=False)
             self.rotary_positional_encoding = holder
-        elif rotary == "LiRE":
-            raise NotImplementedError("rotary_positional_encoding='LiRE' (transformer_blocks.py:350-358) has no HIP "
-                                      "path yet; use None or 'RoPE'")
+        elif rotary == "LiRE":  # transformer_blocks.py:350-357; rotary_embedding_torch.py:337-339
+            hd = E // SLICE_HEADS
+            blk = hd // 2
+            holder = _Params()
+            holder.vars = nn.ParameterList([nn.Parameter(torch.randn((blk * blk - blk) // 2, 33, 1))
+                                            for _ in range(hd // blk)])
+            self.rotary_positional_encoding = holder
         elif rotary is not None:
             raise ValueError(f"Unkown parameter {rotary} for rotary_positional_encoding")
 
@@ -361,8 +365,13 @@ class DinoV2ClassifierSlice(BasicClassifier):
             fw.lin1_w, fw.lin1_b = hip.ptr(f32(lay.linear1.weight)), hip.ptr(f32(lay.linear1.bias))
             fw.lin2_w, fw.lin2_b = hip.ptr(f32(lay.linear2.weight)), hip.ptr(f32(lay.linear2.bias))
             fw.norm_w, fw.norm_b = hip.ptr(f32(self.slice_fusion.norm.weight)), hip.ptr(f32(self.slice_fusion.norm.bias))
-            if hasattr(lay.self_attn, "rotary_positional_encoding"):
-                fw.rope_freqs = hip.ptr(f32(lay.self_attn.rotary_positional_encoding.freqs))
+            rot = getattr(lay.self_attn, "rotary_positional_encoding", None)
+            if rot is not None and hasattr(rot, "freqs"):
+                fw.rope_freqs = hip.ptr(f32(rot.freqs))
+            elif rot is not None:                      # LieRE: R = block_diag(exp(A_blk)) once per weight version
+                R = hip.liere_rotation(list(rot.vars))
+                keep.append(R)
+                fw.liere_rot = hip.ptr(R)
         if isinstance(self.linear, nn.Identity):
             fw.out_ch = 0
         else:

@@ -131,6 +131,15 @@ def synth_state_dict(model_size: str = "s", seed: int = 0, *, img_size: int = 22
             # reference: rotary_embedding_torch.py:105 with theta=256 (transformer_blocks.py:338)
             sd[p + ".self_attn.rotary_positional_encoding.freqs"] = (
                 1.0 / (256 ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd)))
+        elif rotary == "LiRE":
+            # reference: AttentionLiereRotator(head_dim, liere_block_size=head_dim//2, spacial_dims=1, axes_length=33)
+            # (transformer_blocks.py:350-357; rotary_embedding_torch.py:337-339).  std 0.02 keeps the generator
+            # norm (sum over 33 positions weighted by the position index) at a few radians.
+            hd = emb // 12
+            blk = hd // 2
+            for i in range(hd // blk):
+                key = p + f".self_attn.rotary_positional_encoding.vars.{i}"
+                sd[key] = _t(key, ((blk * blk - blk) // 2, 33, 1), seed, 0.02)
         lin(p + ".linear1", emb, emb)
         lin(p + ".linear2", emb, emb)
         ln(p + ".norm1", emb)

@@ -159,6 +159,38 @@ def rope_rotate(t: Tensor, freqs_param: Tensor) -> Tensor:
     return t * ang.cos() + rot * ang.sin()
 
 
+def liere_matrix(vars_: List[Tensor]) -> Tensor:
+    """AttentionLiereRotator's position-independent rotation (rotary_embedding_torch.py:319-326, 357-371):
+    per block, skew generator A[i,j] = sum_p p * x[tril(i,j), p] (i > j), R_blk = matrix_exp(A) in fp32,
+    R = block_diag(R_0, R_1, ...) of size [hd, hd]."""
+    mats = []
+    for v in vars_:
+        n = int(round((1 + math.sqrt(1 + 8 * v.shape[0])) / 2))            # block size from n(n-1)/2 rows
+        pos = torch.arange(v.shape[1], dtype=torch.float32)
+        flat = v[:, :, 0].float() @ pos                                     # [n(n-1)/2]
+        i, j = torch.tril_indices(n, n, offset=-1)
+        A = torch.zeros(n, n)
+        A[i, j] = flat
+        A[j, i] = -flat
+        mats.append(torch.linalg.matrix_exp(A))
+    return torch.block_diag(*mats)
+
+
+def liere_rotate(t: Tensor, R: Tensor, axes_length: int = 33) -> Tensor:
+    """AttentionLiereRotator.rotate_queries_or_keys on [B,h,L,hd] + the caller's reshape
+    (rotary_embedding_torch.py:388-396, 347-386; transformer_blocks.py:263-264).  Every token/head vector is
+    multiplied by the same R; the result is left in [B, L, h, hd] memory order and then VIEWED as
+    [B*h, L, hd] by the caller, which re-partitions (token, head) pairs into pseudo-heads.  Like the
+    reference this only works for L == 33 and B == 1 (the views raise RuntimeError otherwise)."""
+    B, h, L, hd = t.shape
+    x = t.permute(0, 2, 1, 3).contiguous()                                  # l.390
+    x = x.view(B, axes_length, h, hd)                                       # l.349 (RuntimeError unless L == 33)
+    x = x.permute(0, 3, 1, 2)                                               # l.375
+    x = torch.bmm(R[None].repeat(B, 1, 1), x.reshape(B, hd, axes_length * h))   # l.380
+    x = x.view(B, hd, axes_length, h).permute(0, 2, 3, 1)                   # l.381 (a view, not a copy)
+    return x.view(B * h, L, hd).view(B, h, L, hd)                           # transformer_blocks.py:263 (RuntimeError unless B == 1)
+
+
 def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
                  rotary: Optional[str] = None) -> Tuple[Tensor, Tensor]:
     """nn.TransformerEncoder(1 x TransformerEncoderLayer(norm_first), norm=LayerNorm)
@@ -173,6 +205,10 @@ def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
     if rotary == "RoPE":                                                             # l.262-264
         fr = sd[p + ".self_attn.rotary_positional_encoding.freqs"]
         q, k = rope_rotate(q, fr), rope_rotate(k, fr)
+    elif rotary == "LiRE":
+        pre = p + ".self_attn.rotary_positional_encoding.vars."
+        R = liere_matrix([sd[pre + str(i)] for i in range(sum(1 for k in sd if k.startswith(pre)))])
+        q, k = liere_rotate(q, R), liere_rotate(k, R)
     elif rotary is not None:
         raise NotImplementedError(rotary)
     s = (q * math.sqrt(1.0 / hd)) @ k.transpose(-2, -1)                              # l.268-275

@@ -349,3 +349,25 @@ def test_attention_rollout_chain(hip, N, batch, layers):
     assert torch.allclose(out.sum(-1).cpu(), torch.ones(batch, N), atol=1e-4)   # products of stochastic maps stay stochastic
     with pytest.raises(ValueError):
         hip.attention_rollout([maps[0].cuda(), maps[0][:, :, :-1].cuda()])
+
+
+@pytest.mark.parametrize("std", [0.02, 1.0])
+def test_liere_rotation_matches_matrix_exp(hip, std):
+    """R = block_diag(exp(A_blk)) (rotary_embedding_torch.py:319-372) vs an fp64 matrix_exp; std 1.0 is the
+    reference's own init (generator norm in the hundreds: exercises the scaling-and-squaring)."""
+    g = torch.Generator().manual_seed(3)
+    vars_ = [torch.randn(120, 33, 1, generator=g) * std for _ in range(2)]
+    R = hip.liere_rotation([v.cuda() for v in vars_]).cpu().double()
+    pos = torch.arange(33, dtype=torch.float64)
+    blocks = []
+    for v in vars_:
+        flat = v[:, :, 0].double() @ pos
+        i, j = torch.tril_indices(16, 16, offset=-1)
+        A = torch.zeros(16, 16, dtype=torch.float64)
+        A[i, j] = flat
+        A[j, i] = -flat
+        blocks.append(torch.linalg.matrix_exp(A))
+    ref = torch.block_diag(*blocks)
+    assert R.shape == (32, 32)
+    assert (R - ref).abs().max() < 1e-6
+    assert (R @ R.T - torch.eye(32, dtype=torch.float64)).abs().max() < 1e-6   # a rotation

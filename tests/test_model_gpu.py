@@ -28,6 +28,7 @@ CASES = {
     "b2_mask": dict(),
     "bottleneck_pos": dict(use_bottleneck=True, use_slice_pos_emb=True),
     "rope": dict(rotary_positional_encoding="RoPE"),
+    "liere": dict(rotary_positional_encoding="LiRE"),
     "average": dict(slice_fusion="average"),
     "linear32": dict(slice_fusion="linear"),
     "size_b": dict(model_size="b"),
@@ -187,3 +188,13 @@ def test_attention_rollout_matches_reference_fixture(mode):
         plain(src, save_attn=True)
     with pytest.raises(RuntimeError):
         plain.get_attention_cls()
+
+
+def test_liere_restrictions_raise_like_the_reference():
+    """LieRE in the reference only runs for B == 1, D == 32 (errors.json: RuntimeError from its views)."""
+    err = json.loads((GOLDEN / "errors.json").read_text())
+    model = build(dict(rotary_positional_encoding="LiRE"), 9, "fp32")
+    for tag, shape in (("liere_batch2", (2, 1, 32, 28, 28)), ("liere_d16", (1, 1, 16, 28, 28))):
+        assert err[tag]["type"] == "RuntimeError"
+        with pytest.raises(RuntimeError), torch.no_grad():
+            model(torch.zeros(*shape))

@@ -17,6 +17,7 @@ CASES = {  # name -> synth/forward kwargs  (must mirror tools/gen_golden.py)
     "b2_mask": dict(),
     "bottleneck_pos": dict(use_bottleneck=True, use_slice_pos_emb=True),
     "rope": dict(rotary="RoPE"),
+    "liere": dict(rotary="LiRE"),
     "average": dict(slice_fusion="average"),
     "linear32": dict(slice_fusion="linear"),
     "size_b": dict(model_size="b"),
@@ -119,6 +120,16 @@ def test_ops_slice_transformer_layer(tag):
     assert np.abs(ym.numpy() - g[f"tel_{tag}_out_masked"]).max() < 1e-5
     assert np.abs(w.numpy() - g[f"tel_{tag}_weights"]).max() < 5e-6
     assert np.abs(wm.numpy() - g[f"tel_{tag}_weights_masked"]).max() < 5e-6
+
+
+def test_liere_restrictions_match_reference():
+    """The reference's LieRE path only works for B == 1 and D == 32 (views raise RuntimeError otherwise)."""
+    err = json.loads((GOLDEN / "errors.json").read_text())
+    assert err["liere_batch2"]["type"] == err["liere_d16"]["type"] == "RuntimeError"
+    sd = synth.synth_state_dict("s", 9, rotary="LiRE")
+    for shape in ((2, 1, 32, 28, 28), (1, 1, 16, 28, 28)):
+        with pytest.raises(RuntimeError), torch.no_grad():
+            O.forward(sd, torch.zeros(*shape), rotary="LiRE")
 
 
 def test_error_fixture_messages():

@@ -254,6 +254,13 @@ def case_errors(dino, synth):
         dino.DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="l")
     except AssertionError as e:
         res["model_size_l"] = {"type": "AssertionError", "message": str(e)}
+    lm, _ = build(dino, synth, 9, rotary="LiRE")
+    for tag, shape in (("liere_batch2", (2, 1, 32, 28, 28)), ("liere_d16", (1, 1, 16, 28, 28))):
+        try:
+            with torch.no_grad():
+                lm(torch.zeros(*shape))
+        except RuntimeError as e:
+            res[tag] = {"type": "RuntimeError", "message": str(e).splitlines()[0][:120]}
     (GOLD / "errors.json").write_text(json.dumps(res, indent=1))
     print(res)
 
@@ -299,6 +306,7 @@ def main():
                                             plane_subset=[0, 31, 63]),
         "s504_1x4x504": lambda: case_end2end(dino, synth, "s504_1x4x504", (1, 1, 4, 504, 504), 7, chunk=4,
                                              plane_subset=[0, 3]),
+        "liere": lambda: case_end2end(dino, synth, "liere", (1, 1, 32, 56, 56), 9, rotary="LiRE", mask=[5]),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
     }
     for name, fn in cases.items():
