@@ -96,22 +96,21 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 
     // DMA group of step s: everything step s+2 needs = W1 image of producer chunk (s+2)%48 -> W1 slot (s+2)%3 and
     // W2 image of the chunk consumers see at step s+2, i.e. (s+1)%48 -> W2 slot (s+2)%3.  Issued by consumers only.
+    // Branch-free: piece u of consumer k is image piece 4u+k (u < 6: W1, else W2); groups past either end of the
+    // wave's work load a valid but unused chunk into a slot nobody reads again (cheaper than 24 scalar branches).
+    const char* const wp_lane = wpack + pr * 1024 + lane * 16;
+    char* const ring_wave = smem + pr * 1024;
     auto dma_group = [&](int s) {
         const int sp = s + 2;
-        const int slot = sp % NSLOT;
-        const char* s1 = wpack + (size_t)(sp % NCHUNK) * CHUNK_BYTES;
-        const char* s2 = wpack + (size_t)((sp + NCHUNK - 1) % NCHUNK) * CHUNK_BYTES + W1_BYTES;
-        const bool has1 = sp < last, has2 = (sp >= 1) && (sp <= last);
+        const int slot = (sp + NSLOT) % NSLOT;
+        const char* s1 = wp_lane + (size_t)((sp + NCHUNK) % NCHUNK) * CHUNK_BYTES;
+        const char* s2 = wp_lane + (size_t)((sp + NCHUNK - 1) % NCHUNK) * CHUNK_BYTES + W1_BYTES;
+        char* d1 = ring_wave + slot * W1_BYTES;
+        char* d2 = ring_wave + W2_RING + slot * W2_BYTES;
 #pragma unroll
-        for (int u = 0; u < PC; ++u) {
-            const int p = pr * PC + u;                   // piece 0..47: 0..23 = W1 image, 24..47 = W2 image
-            if (p < 24) {
-                if (has1) __builtin_amdgcn_global_load_lds(GLB_PTR(s1 + p * 1024 + lane * 16),
-                                                           LDS_PTR(smem + slot * W1_BYTES + p * 1024), 16, 0, 0);
-            } else {
-                if (has2) __builtin_amdgcn_global_load_lds(GLB_PTR(s2 + (p - 24) * 1024 + lane * 16),
-                                                           LDS_PTR(smem + W2_RING + slot * W2_BYTES + (p - 24) * 1024), 16, 0, 0);
-            }
+        for (int u = 0; u < PC / 2; ++u) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(s1 + u * 4096), LDS_PTR(d1 + u * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(s2 + u * 4096), LDS_PTR(d2 + u * 4096), 16, 0, 0);
         }
     };
     if (!producer) {
