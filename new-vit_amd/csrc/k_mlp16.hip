@@ -41,6 +41,9 @@ constexpr int KS = E / 32;                              // 12 k-steps of GEMM1
 constexpr int NT = E / 16;                              // 24 output tiles (16 columns) of GEMM2
 constexpr int PC = 12;                                  // LDS-DMA pieces per consumer wave per step
 constexpr int DEPTH = 4;                                // fragment reads in flight ahead of the MFMAs
+#ifndef TILE_CYCLES
+#define TILE_CYCLES 150000                              // ~one 128-row tile (48 steps) in shader clocks: the de-phasing window
+#endif
 
 template <int OFF, typename V> __device__ __forceinline__ void lds_read_b128(V& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
@@ -92,30 +95,49 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (my_tiles <= 0) return;
-    const int last = my_tiles * NCHUNK;                  // steps 0 .. last; producers work in [0,last), consumers in [1,last]
+    const int last = my_tiles * NCHUNK;                  // steps 0 .. last+1: GEMM1 of chunk s in [0,last), its GELU + hand-off at s+1, GEMM2 at s+2
 
     // DMA group of step s: everything step s+2 needs = W1 image of producer chunk (s+2)%48 -> W1 slot (s+2)%3 and
-    // W2 image of the chunk consumers see at step s+2, i.e. (s+1)%48 -> W2 slot (s+2)%3.  Issued by consumers only.
+    // W2 image of the chunk consumers see at step s+2, i.e. s%48 -> W2 slot (s+2)%3.  Issued by consumers only.
     // Branch-free: piece u of consumer k is image piece 4u+k (u < 6: W1, else W2); groups past either end of the
     // wave's work load a valid but unused chunk into a slot nobody reads again (cheaper than 24 scalar branches).
     const char* const wp_lane = wpack + pr * 1024 + lane * 16;
     char* const ring_wave = smem + pr * 1024;
-    auto dma_group = [&](int s) {
+    struct DmaGroup { const char* s1; const char* s2; char* d1; char* d2; };
+    auto dma_addr = [&](int s) {
         const int sp = s + 2;
         const int slot = (sp + NSLOT) % NSLOT;
-        const char* s1 = wp_lane + (size_t)((sp + NCHUNK) % NCHUNK) * CHUNK_BYTES;
-        const char* s2 = wp_lane + (size_t)((sp + NCHUNK - 1) % NCHUNK) * CHUNK_BYTES + W1_BYTES;
-        char* d1 = ring_wave + slot * W1_BYTES;
-        char* d2 = ring_wave + W2_RING + slot * W2_BYTES;
+        DmaGroup a;
+        a.s1 = wp_lane + (size_t)((sp + NCHUNK) % NCHUNK) * CHUNK_BYTES;
+        a.s2 = wp_lane + (size_t)((sp + NCHUNK - 2) % NCHUNK) * CHUNK_BYTES + W1_BYTES;
+        a.d1 = ring_wave + slot * W1_BYTES;
+        a.d2 = ring_wave + W2_RING + slot * W2_BYTES;
+        return a;
+    };
+    auto dma_piece = [&](const DmaGroup& a, int u) {     // u = 0..11 (compile-time at the call sites)
+        if (u & 1) __builtin_amdgcn_global_load_lds(GLB_PTR(a.s2 + (u >> 1) * 4096), LDS_PTR(a.d2 + (u >> 1) * 4096), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(GLB_PTR(a.s1 + (u >> 1) * 4096), LDS_PTR(a.d1 + (u >> 1) * 4096), 16, 0, 0);
+    };
+    auto dma_group = [&](int s) {
+        const DmaGroup a = dma_addr(s);
 #pragma unroll
-        for (int u = 0; u < PC / 2; ++u) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(s1 + u * 4096), LDS_PTR(d1 + u * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(s2 + u * 4096), LDS_PTR(d2 + u * 4096), 16, 0, 0);
-        }
+        for (int u = 0; u < PC; ++u) dma_piece(a, u);
     };
     if (!producer) {
         dma_group(-2);
         dma_group(-1);
+    }
+
+    // De-phase the persistent workgroups.  All of them walk the same 48-step tiles, so without this every CU reads its
+    // LayerNorm rows and writes its epilogue at the same moment: HBM sees bursts at its full rate while the MFMAs
+    // idle, then nothing for 48 steps.  A one-off start delay spreads the tile boundaries over the tile period;
+    // the workgroups that own one tile fewer take the later half of the phases, so the tail stays balanced.
+    if (my_tiles >= 4) {
+        const int min_tiles = ntiles / (int)gridDim.x;
+        const unsigned u = (((unsigned)blockIdx.x >> 3) + 5u * ((unsigned)blockIdx.x & 7u)) & 15u;   // 0..15
+        const unsigned long long delay = (unsigned long long)TILE_CYCLES * ((my_tiles > min_tiles ? 0u : 16u) + u) / 32u;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
     }
 
     // The two roles run two separate step loops (same number of s_barriers: one per step 0..last), so the
@@ -131,10 +153,20 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 #ifdef MLP_STAMPS
         unsigned long long st[4] = {0, 0, 0, 0};
 #endif
+        f32x4 hp[2][2] = {};                             // pre-activations of the previous chunk [hidden tile][row tile]
+        auto store_h = [&](const float (&gv)[16], int sc) {   // k order of GEMM2 = (hidden tile, register) order of GEMM1
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                vec8 hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = (T)gv[8 * mt + j];
+                *reinterpret_cast<vec8*>(hslot + mt * 1024 + (sc & 1) * 8192) = hv;
+            }
+        };
 #pragma unroll 1
-        for (int s = 0; s <= last; ++s) {
+        for (int s = 0; s <= last + 1; ++s) {
             STAMP(t0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // H(s-1) writes drained before the hand-off
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // H(s-2) writes drained before the hand-off
             STAMP(t1);
             ACCUM(0, t0, t1);
             if (s < last) {
@@ -142,15 +174,23 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                 if (c == 0) {
                     // ---- LayerNorm of this pair's 32 rows of tile s/48 -> GEMM1 B-operand fragments
                     const int tile = blockIdx.x + (s / NCHUNK) * gridDim.x;
+                    float4 raw[2][2 * KS];               // both row tiles' 48 loads in flight together (one HBM round trip)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const int m = tile * 128 + pr * 32 + 16 * mt + frow;
                         const float* xr = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            raw[mt][2 * ks] = *reinterpret_cast<const float4*>(xr + 32 * ks);
+                            raw[mt][2 * ks + 1] = *reinterpret_cast<const float4*>(xr + 32 * ks + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
                         float v[KS * 8];
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
-                            const float4 a = *reinterpret_cast<const float4*>(xr + 32 * ks);
-                            const float4 b = *reinterpret_cast<const float4*>(xr + 32 * ks + 4);
+                            const float4 a = raw[mt][2 * ks], b = raw[mt][2 * ks + 1];
                             v[8 * ks + 0] = a.x; v[8 * ks + 1] = a.y; v[8 * ks + 2] = a.z; v[8 * ks + 3] = a.w;
                             v[8 * ks + 4] = b.x; v[8 * ks + 5] = b.y; v[8 * ks + 6] = b.z; v[8 * ks + 7] = b.w;
                         }
@@ -186,6 +226,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                     bias_next[1] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 16 + 4 * g);
                 }
                 f32x4 h[2][2] = {{b0, b0}, {b1v, b1v}};  // [hidden tile][row tile]
+                float gv[16];                            // GELU of the PREVIOUS chunk, interleaved with this chunk's MFMAs
                 const unsigned w1a = lds_base + (s % NSLOT) * W1_BYTES + frag_off;
                 vec8 w[2 * KS];                          // fragment index q = 2*ks + ht  ->  byte offset ks*2048 + ht*1024
                 wait_lgkm<0>();
@@ -196,21 +237,25 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                     wait_lgkm<(2 * KS - 1 - q < DEPTH) ? (2 * KS - 1 - q) : DEPTH>();
                     h[q & 1][0] = mfma16(w[q], __builtin_bit_cast(vec8, XA(0, q >> 1)), h[q & 1][0]);
                     h[q & 1][1] = mfma16(w[q], __builtin_bit_cast(vec8, XA(1, q >> 1)), h[q & 1][1]);
+                    if constexpr (q % 3 != 2) {          // 16 of the 24 iterations carry one GELU each (VALU under the MFMAs;
+                        constexpr int e = q - q / 3;     // packed v_pk_fma_f32 pairs measured 4 % slower than scalar FMAs here)
+                        gv[e] = gelu_poly(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                    }
                 });
                 STAMP(t3);
-                ACCUM(2, t2, t3);                        // GEMM1
+                ACCUM(2, t2, t3);                        // GEMM1 (+ GELU of the previous chunk)
+                store_h(gv, s - 1);                      // H(s-1); at s == 0 a dummy into the parity nobody reads yet
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    vec8 hv;                             // k order of GEMM2 = (hidden tile, register) order of GEMM1
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hv[r] = (T)gelu_poly(h[0][mt][r]);
-                        hv[4 + r] = (T)gelu_poly(h[1][mt][r]);
-                    }
-                    *reinterpret_cast<vec8*>(hslot + mt * 1024 + (s & 1) * 8192) = hv;
-                }
+                    for (int j = 0; j < 2; ++j) hp[i][j] = h[i][j];
                 STAMP(t4);
-                ACCUM(3, t3, t4);                        // GELU + hand-off
+                ACCUM(3, t3, t4);                        // hand-off
+            } else if (s == last) {                      // drain: GELU + hand-off of the last chunk
+                float gv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) gv[e] = gelu_poly(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                store_h(gv, s - 1);
             }
         }
 #ifdef MLP_STAMPS
@@ -222,8 +267,10 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
         unsigned long long st[4] = {0, 0, 0, 0};
 #endif
 #pragma unroll 1
-        for (int s = 0; s <= last; ++s) {
+        for (int s = 0; s <= last + 1; ++s) {
             STAMP(t0);
+            // this wave's pieces of group s-2 have landed (group s-1, the newest 12 VMEM ops, may stay in flight; at a tile
+            // boundary the epilogue's stores are newer still, which only makes this wait stricter)
             if (s >= 2 && s <= last - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -231,15 +278,26 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
             ACCUM(0, t0, t1);                            // DMA wait + barrier
             dma_group(s);
             STAMP(t2);
-            ACCUM(1, t1, t2);                            // DMA issue
-            if (s >= 1) {
-                const int sc = s - 1, c = sc % NCHUNK;
-                if (c == 0) {                            // new tile: accumulators start at b2
+            ACCUM(1, t1, t2);                            // DMA addresses
+            if (s >= 2) {
+                const int sc = s - 2, c = sc % NCHUNK;
+                if (c == 0) {
+                    // new tile: accumulators start at x + b2 (the residual rides in the accumulators, so all 48 row
+                    // pieces are in flight at once here and the epilogue is store-only: no 12 dependent HBM round trips)
+                    const int tile = blockIdx.x + (sc / NCHUNK) * gridDim.x;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int m = tile * 128 + pr * 32 + 16 * mt + frow;
+                        const float* xr = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            ACC(t, mt) = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(xr + 32 * (t >> 1) + 4 * (t & 1)));
+                    }
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
-                        ACC(t, 0) = __builtin_bit_cast(u32x4, bv);
-                        ACC(t, 1) = __builtin_bit_cast(u32x4, bv);
+                        ACC(t, 0) = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, ACC(t, 0)) + bv);
+                        ACC(t, 1) = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, ACC(t, 1)) + bv);
                     }
                 }
                 // ---- GEMM2 of chunk c
@@ -259,30 +317,16 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                 STAMP(t3);
                 ACCUM(2, t2, t3);                        // GEMM2
                 if (c == NCHUNK - 1) {
-                    // ---- epilogue of tile sc/48: residual (+ LayerScale), store x, next LayerNorm from registers
+                    // ---- epilogue of tile sc/48: store x (residual already inside), next LayerNorm from registers
                     const int tile = blockIdx.x + (sc / NCHUNK) * gridDim.x;
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const int m = tile * 128 + pr * 32 + 16 * mt + frow;
                         float* xw = x + (size_t)(m < M ? m : M - 1) * E + 8 * g;
+                        if (m < M) {
 #pragma unroll
-                        for (int kb = 0; kb < KS; kb += 4) {
-                            float4 xo[8];
-#pragma unroll
-                            for (int k2 = 0; k2 < 8; ++k2) xo[k2] = *reinterpret_cast<const float4*>(xw + 32 * (kb + (k2 >> 1)) + 4 * (k2 & 1));
-#pragma unroll
-                            for (int k2 = 0; k2 < 8; ++k2) {
-                                const int t = 2 * kb + k2;
-                                float4 gs = make_float4(1.f, 1.f, 1.f, 1.f);
-                                if (ls2) gs = *reinterpret_cast<const float4*>(ls2 + 32 * (t >> 1) + 8 * g + 4 * (t & 1));
-                                f32x4 a = __builtin_bit_cast(f32x4, ACC(t, mt));
-                                a[0] = xo[k2].x + gs.x * a[0];
-                                a[1] = xo[k2].y + gs.y * a[1];
-                                a[2] = xo[k2].z + gs.z * a[2];
-                                a[3] = xo[k2].w + gs.w * a[3];
-                                ACC(t, mt) = __builtin_bit_cast(u32x4, a);
-                                if (m < M) *reinterpret_cast<float4*>(xw + 32 * (t >> 1) + 4 * (t & 1)) = make_float4(a[0], a[1], a[2], a[3]);
-                            }
+                            for (int t = 0; t < NT; ++t)
+                                *reinterpret_cast<f32x4*>(xw + 32 * (t >> 1) + 4 * (t & 1)) = __builtin_bit_cast(f32x4, ACC(t, mt));
                         }
                         if (xn_out) {
                             float sum = 0.f;
