@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                     h[q & 1][1] = mfma16(w[q], __builtin_bit_cast(vec8, XA(1, q >> 1)), h[q & 1][1]);
                     if constexpr (q % 3 != 2) {          // 16 of the 24 iterations carry one GELU each (VALU under the MFMAs;
                         constexpr int e = q - q / 3;     // packed v_pk_fma_f32 pairs measured 4 % slower than scalar FMAs here)
-                        gv[e] = gelu_poly(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                        gv[e] = gelu_sig<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
                     }
                 });
                 STAMP(t3);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
             } else if (s == last) {                      // drain: GELU + hand-off of the last chunk
                 float gv[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) gv[e] = gelu_poly(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                for (int e = 0; e < 16; ++e) gv[e] = gelu_sig<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
                 store_h(gv, s - 1);
             }
         }
