@@ -39,7 +39,8 @@ constexpr int HBUF = 2 * NSLOT * W1_BYTES;              // byte offset of the H 
 constexpr int LDS_BYTES = HBUF + 2 * 8192;              // 163,840 = all of the LDS
 constexpr int KS = E / 32;                              // 12 k-steps of GEMM1
 constexpr int NT = E / 16;                              // 24 output tiles (16 columns) of GEMM2
-constexpr int PC = 12;                                  // LDS-DMA pieces per consumer wave per step
+constexpr int PC_CONS = 12;                             // LDS-DMA pieces per step issued by each consumer wave (of 12 per wave pair)
+constexpr int PC_PROD = 12 - PC_CONS;
 constexpr int DEPTH = 4;                                // fragment reads in flight ahead of the MFMAs
 #ifndef TILE_CYCLES
 #define TILE_CYCLES 150000                              // ~one 128-row tile (48 steps) in shader clocks: the de-phasing window
@@ -114,19 +115,24 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
         a.d2 = ring_wave + W2_RING + slot * W2_BYTES;
         return a;
     };
-    auto dma_piece = [&](const DmaGroup& a, int u) {     // u = 0..11 (compile-time at the call sites)
-        if (u & 1) __builtin_amdgcn_global_load_lds(GLB_PTR(a.s2 + (u >> 1) * 4096), LDS_PTR(a.d2 + (u >> 1) * 4096), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds(GLB_PTR(a.s1 + (u >> 1) * 4096), LDS_PTR(a.d1 + (u >> 1) * 4096), 16, 0, 0);
+    auto dma_piece = [&](const DmaGroup& a, int u) {     // image piece 4u + (wave & 3), u = 0..11 (compile-time): u < 6 W1, else W2
+        if (u < 6) __builtin_amdgcn_global_load_lds(GLB_PTR(a.s1 + u * 4096), LDS_PTR(a.d1 + u * 4096), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(GLB_PTR(a.s2 + (u - 6) * 4096), LDS_PTR(a.d2 + (u - 6) * 4096), 16, 0, 0);
     };
+    // The issue cost of a piece (~85 cycles inside these loops) is paid by the issuing wave only, so the 48 pieces of a
+    // step are split to level the two roles' step times: consumers take PC_CONS each, producers the rest.
     auto dma_group = [&](int s) {
         const DmaGroup a = dma_addr(s);
+        if (producer) {
 #pragma unroll
-        for (int u = 0; u < PC; ++u) dma_piece(a, u);
+            for (int u = PC_CONS; u < 12; ++u) dma_piece(a, u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PC_CONS; ++u) dma_piece(a, u);
+        }
     };
-    if (!producer) {
-        dma_group(-2);
-        dma_group(-1);
-    }
+    dma_group(-2);
+    dma_group(-1);
 
     // De-phase the persistent workgroups.  All of them walk the same 48-step tiles, so without this every CU reads its
     // LayerNorm rows and writes its epilogue at the same moment: HBM sees bursts at its full rate while the MFMAs
@@ -166,6 +172,11 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 #pragma unroll 1
         for (int s = 0; s <= last + 1; ++s) {
             STAMP(t0);
+            // this wave's pieces of group s-2 have landed; group s-1 (the newest PC_PROD VMEM ops) may stay in flight
+            if constexpr (PC_PROD > 0) {
+                if (s <= last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC_PROD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // H(s-2) writes drained before the hand-off
             STAMP(t1);
             ACCUM(0, t0, t1);
@@ -225,6 +236,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
                     bias_next[0] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 4 * g);
                     bias_next[1] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 16 + 4 * g);
                 }
+                dma_group(s);                            // after this step's other loads: they stay older than the pieces
                 f32x4 h[2][2] = {{b0, b0}, {b1v, b1v}};  // [hidden tile][row tile]
                 float gv[16];                            // GELU of the PREVIOUS chunk, interleaved with this chunk's MFMAs
                 const unsigned w1a = lds_base + (s % NSLOT) * W1_BYTES + frag_off;
@@ -269,9 +281,9 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 #pragma unroll 1
         for (int s = 0; s <= last + 1; ++s) {
             STAMP(t0);
-            // this wave's pieces of group s-2 have landed (group s-1, the newest 12 VMEM ops, may stay in flight; at a tile
+            // this wave's pieces of group s-2 have landed (group s-1, the newest PC_CONS VMEM ops, may stay in flight; at a tile
             // boundary the epilogue's stores are newer still, which only makes this wait stricter)
-            if (s >= 2 && s <= last - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC) : "memory");
+            if (s >= 2 && s <= last - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PC_CONS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             STAMP(t1);
