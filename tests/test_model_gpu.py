@@ -35,6 +35,12 @@ CASES = {
 }
 
 
+# The LieRE slice transformer (33 tokens re-partitioned into pseudo-heads) amplifies a given embedding error about
+# 2-4x more into the logits than the other fusions do (tools/fixture_errors.py: same 1.8e-3 embedding error in fp16,
+# 5.6e-3 on the logits vs <= 2.9e-3 elsewhere), so its logits tolerance is doubled in the 16-bit modes only.
+LOGIT_SCALE = {"liere": {"fp16": 2.0, "bf16": 2.0}}
+
+
 def build(name_kwargs, seed, mode, **extra):
     from mst.models import DinoV2ClassifierSlice
     kw = dict(name_kwargs)
@@ -53,6 +59,7 @@ def build(name_kwargs, seed, mode, **extra):
 def test_forward_matches_reference_fixture(name, mode):
     g = load_golden(name)
     tl, te, tm = TOL[mode]
+    tl *= LOGIT_SCALE.get(name, {}).get(mode, 1.0)
     model = build(CASES[name], int(g["seed"]), mode)
     src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
     mask = torch.from_numpy(g["src_key_padding_mask"]) if "src_key_padding_mask" in g else None
