@@ -76,10 +76,17 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: using WORLD_SIZE", file=sys.stderr)
     n_gpus = world
+    # rehearsal hooks (never set by the driver): all ranks on one GPU over gloo, to exercise the sharded path on a 1-GPU box
+    backend = os.environ.get("MST_BENCH_BACKEND", "nccl")
+    if os.environ.get("MST_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mst import hip, synth
     from mst.models import DinoV2ClassifierSlice

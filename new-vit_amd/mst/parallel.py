@@ -32,8 +32,14 @@ class SliceSharding:
         """local [B, dpad, X] (this rank's shard, zero-padded to dpad) -> [B, D, X] on every rank."""
         B, dpad, X = local.shape
         local = local.contiguous()
+        dev = local.device
+        if dev.type == "cuda" and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks on ONE GPU, where RCCL refuses duplicate devices): gloo has no CUDA
+            # all_gather, so the 100-KB message takes the host path.  The product path is backend "nccl" (= RCCL).
+            local = local.cpu()
         out = torch.empty((self.world_size * B, dpad, X), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=self.group)  # rank-major concatenation on dim 0
+        out = out.to(dev)
         out = out.view(self.world_size, B, dpad, X)
         return out.permute(1, 0, 2, 3).reshape(B, self.world_size * dpad, X)[:, :D].contiguous()
 

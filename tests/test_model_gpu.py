@@ -205,3 +205,41 @@ def test_liere_restrictions_raise_like_the_reference():
         assert err[tag]["type"] == "RuntimeError"
         with pytest.raises(RuntimeError), torch.no_grad():
             model(torch.zeros(*shape))
+
+
+def _shard_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share cuda:0: RCCL refuses duplicate devices
+    torch.cuda.set_device(0)
+    g = load_golden("b2_mask")
+    model = build(CASES["b2_mask"], int(g["seed"]), "fp16")
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    with torch.no_grad():
+        ref = model(src, src_key_padding_mask=mask, save_attn=True)
+        ref_maps = model.get_attention_maps()
+        model.enable_slice_sharding()
+        out = model(src, src_key_padding_mask=mask, save_attn=True)      # D = 6 over 2 ranks; with 4 ranks it would be ragged
+        maps = model.get_attention_maps()
+    ret[rank] = (bool(torch.equal(out, ref)), bool(torch.equal(maps, ref_maps)), float((out.cpu() - torch.from_numpy(g["logits"])).abs().max()))
+    dist.destroy_process_group()
+
+
+def test_slice_sharded_forward_equals_unsharded_two_ranks_one_gpu():
+    """slices sharded over ranks + all-gather of embeddings / CLS rows must reproduce the single-rank
+    forward bit-for-bit (slices are independent in the encoder; the fusion stage is replicated)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, 29533, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(2):
+        same_logits, same_maps, err = ret[r]
+        assert same_logits and same_maps, (r, ret[r])
+        assert err < TOL["fp16"][0]
