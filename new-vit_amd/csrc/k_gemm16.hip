@@ -214,7 +214,7 @@ int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw
     // HBM-bound and overlaps better with two small workgroups per CU; the others favour the big tile
     static const bool mid_ok = !(getenv("MST_GEMM_MID") && atoi(getenv("MST_GEMM_MID")) == 0);
     if (mid_ok && gemm16_mid_applicable(M, N, K, dt, cdt, epi))
-        return launch_gemm16_mid(A, dt, lda, W, ldw, bias, C, ldc, M, N, K, epi, col_scale, scale_cols, s);
+        return launch_gemm16_mid(A, dt, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     if (big_ok && epi != MST_EPI_RESIDUAL && gemm16_big_applicable(M, N, K))
         return launch_gemm16_big(A, dt, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     if (dt == MST_BF16) return dispatch<bf16_t>(A, lda, W, ldw, bias, C, cdt, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);

@@ -1,4 +1,4 @@
-// Mid-tile 16-bit MFMA GEMM (contract of k_gemm16.hip, 16-bit outputs, bias / ReLU epilogues) for the QKV projection
+// Mid-tile 16-bit MFMA GEMM (contract of k_gemm16.hip; 16-bit outputs with bias / ReLU epilogues, fp32 output with the residual epilogue) for the QKV projection
 // (M ~ 10^5, N = 1152, K = 384): tile 128 x 384, ONE 4-wave workgroup per CU, one wave per SIMD.
 //
 // Why: with K = 384 the persistent 256 x 384 kernel (k_gemm16_big.hip, 8 waves at 256 VGPRs) and the 128 x 128 kernel
@@ -25,8 +25,7 @@ constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
 #endif
 constexpr int NSTAGE = MID_NSTAGE;
 constexpr int STG_OFF = NSTAGE * STAGE_BYTES;     // epilogue staging behind the ring
-constexpr int ROWB = 96 * 2 + 16;                 // padded staging row (208 B)
-constexpr int LDS_BYTES = STG_OFF + 4 * 16 * ROWB;   // ring + 13 KiB of staging
+constexpr int LDS_BYTES = STG_OFF + 4 * 16 * (96 * 4 + 16);   // ring + staging (25.6 KiB covers fp32 rows)
 constexpr int NI = 6, NJ = 8;                     // 16-wide sub-tiles per wave: N, M
 constexpr int PA = 2, PW = 6, PS = PA + PW;       // LDS-DMA pieces per wave per stage: A, W, total
 #ifndef MID_NBLK
@@ -34,12 +33,12 @@ constexpr int PA = 2, PW = 6, PS = PA + PW;       // LDS-DMA pieces per wave per
 #endif
 constexpr int NBLK = MID_NBLK;
 
-template <typename T, int EPI>
+template <typename T, int EPI, typename OutT>
 __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A, int64_t lda,
                                                          const T* __restrict__ W, int64_t ldw,
-                                                         const float* __restrict__ bias, T* C, int64_t ldc, int M,
-                                                         int N, int K, float col_scale, int scale_cols, int tiles_n,
-                                                         int ntiles) {
+                                                         const float* __restrict__ bias, OutT* C, int64_t ldc, int M,
+                                                         int N, int K, const float* __restrict__ gamma, float col_scale,
+                                                         int scale_cols, int tiles_n, int ntiles) {
     typedef typename V8<T>::type vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -136,12 +135,15 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
                 if (u < nk) stage((ring + u) % NSTAGE, u);
         }
 
-        // ---- epilogue: each wave transposes one 16-row x 96-column slab at a time through its private staging area
+        // ---- epilogue: each wave transposes one 16-row x 96-column slab at a time through its private staging area and
+        // moves it to / from global memory as 16-byte lane accesses along whole row segments (fp32: 384 B = three lines)
         {
-            constexpr int CPR = 96 * 2 / 16;              // 16-byte chunks per row (12)
-            constexpr int NCH = 16 * CPR / 64;            // chunk instructions per slab (3)
+            constexpr int OB = (int)sizeof(OutT);
+            constexpr int ROWB = 96 * OB + 16;            // padded staging row (400 B fp32 / 208 B 16-bit)
+            constexpr int CPR = 96 * OB / 16;             // 16-byte chunks per row (24 / 12)
+            constexpr int NCH = 16 * CPR / 64;            // chunk instructions per slab (6 / 3)
             char* stg = smem + STG_OFF + wave * (16 * ROWB);
-            const int wr_off = (lane & 15) * ROWB + (lane >> 4) * 8;
+            const int wr_off = (lane & 15) * ROWB + (lane >> 4) * 4 * OB;
             const int n_w = n0 + wave * 96;
             auto slabs = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;   // interior tile: no per-lane row guards
@@ -153,16 +155,29 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             if (nb + i * 16 + r < scale_cols) v[r] *= col_scale;
-                            if (EPI == MST_EPI_BIAS_GELU) v[r] = gelu_fast(v[r]);
                             if (EPI == MST_EPI_BIAS_RELU) v[r] = fmaxf(v[r], 0.f);
                         }
-                        typedef __attribute__((ext_vector_type(4))) T o4;
-                        o4 pk;
-                        pk[0] = (T)v[0];
-                        pk[1] = (T)v[1];
-                        pk[2] = (T)v[2];
-                        pk[3] = (T)v[3];
-                        *reinterpret_cast<o4*>(stg + wr_off + i * 32) = pk;
+                        if constexpr (OB == 4) {
+                            *reinterpret_cast<float4*>(stg + wr_off + i * 64) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            typedef __attribute__((ext_vector_type(4))) OutT o4;
+                            o4 pk;
+                            pk[0] = (OutT)v[0];
+                            pk[1] = (OutT)v[1];
+                            pk[2] = (OutT)v[2];
+                            pk[3] = (OutT)v[3];
+                            *reinterpret_cast<o4*>(stg + wr_off + i * 32) = pk;
+                        }
+                    }
+                    float4 xv[NCH];
+                    if constexpr (EPI == MST_EPI_RESIDUAL) {   // all read-modify-write loads of the slab first
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int q = c * 64 + lane;
+                            const int row = q / CPR, ch = q - row * CPR;
+                            const int m = m0 + j * 16 + row;
+                            if (FULL || m < M) xv[c] = *reinterpret_cast<const float4*>(C + (int64_t)m * ldc + n_w + ch * 4);
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
@@ -171,7 +186,19 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
                         const int m = m0 + j * 16 + row;
                         const u32x4 tv = *reinterpret_cast<const u32x4*>(stg + row * ROWB + ch * 16);
                         if (!FULL && m >= M) continue;
-                        *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n_w + ch * 8) = tv;
+                        OutT* cp = C + (int64_t)m * ldc + n_w + ch * (16 / OB);
+                        if constexpr (EPI == MST_EPI_RESIDUAL) {
+                            float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (gamma) gv = *reinterpret_cast<const float4*>(gamma + n_w + ch * 4);
+                            float4 o;
+                            o.x = xv[c].x + gv.x * __uint_as_float(tv[0]);
+                            o.y = xv[c].y + gv.y * __uint_as_float(tv[1]);
+                            o.z = xv[c].z + gv.z * __uint_as_float(tv[2]);
+                            o.w = xv[c].w + gv.w * __uint_as_float(tv[3]);
+                            *reinterpret_cast<float4*>(cp) = o;
+                        } else {
+                            *reinterpret_cast<u32x4*>(cp) = tv;
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -186,11 +213,11 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
-             int N, int K, float cs, int sc, hipStream_t s) {
+             int N, int K, const float* gamma, float cs, int sc, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = gemm16_mid_kernel<T, EPI>;
+    auto kern = gemm16_mid_kernel<T, EPI, OutT>;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
@@ -198,18 +225,18 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
     int nblk = ntiles < NBLK ? ((ntiles + 7) / 8) * 8 : NBLK;
-    kern<<<dim3(nblk), dim3(256), LDS_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (T*)C, ldc, (int)M, N, K, cs, sc,
-                                                   tiles_n, ntiles);
+    kern<<<dim3(nblk), dim3(256), LDS_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma,
+                                                   cs, sc, tiles_n, ntiles);
     return mst_check_launch("gemm16_mid");
 }
 
 template <typename T>
 int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
-             int N, int K, int epi, float cs, int sc, hipStream_t s) {
+             int N, int K, int epi, const float* gamma, float cs, int sc, hipStream_t s) {
     switch (epi) {
-        case MST_EPI_BIAS: return launch_t<T, MST_EPI_BIAS>(A, lda, W, ldw, bias, C, ldc, M, N, K, cs, sc, s);
-        case MST_EPI_BIAS_GELU: return launch_t<T, MST_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, cs, sc, s);
-        case MST_EPI_BIAS_RELU: return launch_t<T, MST_EPI_BIAS_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, cs, sc, s);
+        case MST_EPI_BIAS: return launch_t<T, MST_EPI_BIAS, T>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+        case MST_EPI_BIAS_RELU: return launch_t<T, MST_EPI_BIAS_RELU, T>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
+        case MST_EPI_RESIDUAL: return launch_t<T, MST_EPI_RESIDUAL, float>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, cs, sc, s);
     }
     mst_set_error("gemm16_mid: bad epilogue %d", epi);
     return MST_EINVAL;
@@ -220,14 +247,18 @@ int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float
 // true when the two-per-CU kernel applies: 16-bit output of the operand type, shallow K (the epilogue weighs as much as
 // the K-loop), enough tiles to fill the chip twice
 bool gemm16_mid_applicable(int64_t M, int N, int K, int dt, int cdt, int epi) {
-    return dt == cdt && (epi == MST_EPI_BIAS || epi == MST_EPI_BIAS_RELU) && (N % BN == 0) && (K % BK == 0) && K <= 512 &&
+    // the residual (fp32 read-modify-write) epilogue is implemented too, but the HBM-bound proj GEMM measured the same on
+    // this kernel and on the 128 x 128 one (0.33 ms), so it stays there
+    const bool out_ok = dt == cdt && (epi == MST_EPI_BIAS || epi == MST_EPI_BIAS_RELU);
+    return out_ok && (N % BN == 0) && (K % BK == 0) && K <= 512 &&
            ((M + BM - 1) / BM) * (int64_t)(N / BN) >= 512;
 }
 
 int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
-                      int64_t ldc, int64_t M, int N, int K, int epi, float col_scale, int scale_cols, hipStream_t s) {
-    if (dt == MST_BF16) return dispatch<bf16_t>(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, col_scale, scale_cols, s);
-    if (dt == MST_F16) return dispatch<f16_t>(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, col_scale, scale_cols, s);
+                      int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols,
+                      hipStream_t s) {
+    if (dt == MST_BF16) return dispatch<bf16_t>(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
+    if (dt == MST_F16) return dispatch<f16_t>(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     mst_set_error("gemm16_mid: bad operand dtype %d", dt);
     return MST_EINVAL;
 }

@@ -148,7 +148,8 @@ int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t
                       float col_scale, int scale_cols, hipStream_t s);
 bool gemm16_mid_applicable(int64_t M, int N, int K, int dt, int cdt, int epi);
 int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
-                      int64_t ldc, int64_t M, int N, int K, int epi, float col_scale, int scale_cols, hipStream_t s);
+                      int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols,
+                      hipStream_t s);
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
