@@ -202,6 +202,17 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
                           int heads, int N, int num_registers, int sheads, float* plane,
                           float* slice_attn, float* maps, mst_stream_t stream);
 
+/* Saliency volume of `--get_attention` (scripts/main_predict.py:72-105, 147-165: what _pred_trans / run_pred do after
+ * the forward of ONE volume).  mst_saliency_accumulate: lowres[D, gh, gw] (+)= head-mean of maps fp32 [D, heads, Np]
+ * (the get_attention_maps() result; columns >= gh*gw ignored, l.94-96) with the axes named in flip_mask (bit 0 depth,
+ * bit 1 height, bit 2 width) mirrored back -- the test-time-augmentation sum of l.147-153; slice_acc[D] (+)= slice_attn[D]
+ * likewise (nullable).  accumulate = 0 overwrites.  mst_saliency_upsample: out fp32 [Dout, H, W] = scale * trilinear
+ * (align_corners=False, F.interpolate at l.163) of lowres. */
+int mst_saliency_accumulate(const float* maps, const float* slice_attn, int D, int heads, int gh, int gw, int Np,
+                            int flip_mask, int accumulate, float* lowres, float* slice_acc, mst_stream_t stream);
+int mst_saliency_upsample(const float* lowres, int D, int gh, int gw, float scale, int Dout, int H, int W, float* out,
+                          mst_stream_t stream);
+
 /* LieRE rotation of the slice transformer (AttentionLiereRotator, rotary_embedding_torch.py:319-372;
  * transformer_blocks.py:350-357): vars fp32 [n_blocks, block(block-1)/2, axes_length] (the module's ParameterList
  * stacked; spacial_dims = 1) -> R fp32 [n_blocks*block, n_blocks*block], block-diagonal, R_blk = exp(A_blk) with the

@@ -334,6 +334,22 @@ int mst_attention_readout(const float* cls_probs_last, const float* slice_probs,
                           (hipStream_t)stream);
 }
 
+int mst_saliency_accumulate(const float* maps, const float* slice_attn, int D, int heads, int gh, int gw, int Np,
+                            int flip_mask, int accumulate, float* lowres, float* slice_acc, mst_stream_t stream) {
+    MST_CHECK_ARG(maps && lowres && (slice_attn || !slice_acc), "saliency_accumulate: null pointer");
+    MST_CHECK_ARG(D > 0 && heads > 0 && gh > 0 && gw > 0 && gh * gw <= Np, "saliency_accumulate: grid %d x %d does not fit %d map columns", gh, gw, Np);
+    MST_CHECK_ARG((flip_mask & ~7) == 0, "saliency_accumulate: flip_mask %d", flip_mask);
+    return launch_saliency_accumulate(maps, slice_attn, D, heads, gh, gw, Np, flip_mask, accumulate, lowres, slice_acc,
+                                      (hipStream_t)stream);
+}
+
+int mst_saliency_upsample(const float* lowres, int D, int gh, int gw, float scale, int Dout, int H, int W, float* out,
+                          mst_stream_t stream) {
+    MST_CHECK_ARG(lowres && out, "saliency_upsample: null pointer");
+    MST_CHECK_ARG(D > 0 && gh > 0 && gw > 0 && Dout > 0 && H > 0 && W > 0, "saliency_upsample: bad sizes");
+    return launch_saliency_upsample(lowres, D, gh, gw, scale, Dout, H, W, out, (hipStream_t)stream);
+}
+
 int mst_liere_rotation(const float* vars, int n_blocks, int block, int axes_length, float* R, mst_stream_t stream) {
     MST_CHECK_ARG(vars && R, "liere_rotation: null pointer");
     return launch_liere_rotation(vars, n_blocks, block, axes_length, R, (hipStream_t)stream);

@@ -173,6 +173,10 @@ int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const u
 int launch_liere_rotation(const float* vars, int n_blocks, int n, int P, float* R, hipStream_t s);
 int launch_rows_copy(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int rows,
                      int cols, hipStream_t s);
+int launch_saliency_accumulate(const float* maps, const float* slice_attn, int D, int heads, int gh, int gw, int Np,
+                               int flip_mask, int accumulate, float* low, float* slice_acc, hipStream_t s);
+int launch_saliency_upsample(const float* low, int D, int gh, int gw, float scale, int Dout, int H, int W, float* out,
+                             hipStream_t s);
 int launch_bmm32_nn(const float* A, const float* B, float* C, int64_t batch, int M, int N, int K, hipStream_t s);
 int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
 int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,

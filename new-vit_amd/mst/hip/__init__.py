@@ -66,6 +66,8 @@ SIGNATURES = {
     "mst_fusion_workspace_bytes": (_sz, [C.POINTER(FusionWeights), _i, _i]),
     "mst_slice_fusion": (_i, [C.POINTER(FusionWeights), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mst_attention_readout": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mst_saliency_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mst_saliency_upsample": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "mst_liere_rotation": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_attention_rollout": (_i, [C.POINTER(_vp), _i, _i64, _i, _vp, _vp, _vp]),
     "mst_profile_enable": (_i, [_i]),
@@ -268,6 +270,26 @@ def attention_readout(cls_probs_last: Optional[torch.Tensor], slice_probs: Optio
     t = cls_probs_last if cls_probs_last is not None else slice_probs
     _check(load().mst_attention_readout(ptr(cls_probs_last), ptr(slice_probs), B, D, heads, N, num_registers, sheads,
                                         ptr(plane), ptr(slice_attn), ptr(maps), stream_of(t)), "mst_attention_readout")
+
+
+def saliency_accumulate(maps: torch.Tensor, slice_attn: Optional[torch.Tensor], gh: int, gw: int, flip_mask: int,
+                        lowres: torch.Tensor, slice_acc: Optional[torch.Tensor], accumulate: bool):
+    """lowres [D,gh,gw] (+)= head-mean of maps [D,heads,Np], TTA flips (bit 0 depth, 1 height, 2 width) mirrored back."""
+    _dev(maps, "saliency_accumulate")
+    D, heads, Np = maps.shape
+    _check(load().mst_saliency_accumulate(ptr(maps), ptr(slice_attn), D, heads, gh, gw, Np, flip_mask, 1 if accumulate else 0,
+                                          ptr(lowres), ptr(slice_acc), stream_of(maps)), "mst_saliency_accumulate")
+
+
+def saliency_upsample(lowres: torch.Tensor, size, scale: float = 1.0) -> torch.Tensor:
+    """scale * F.interpolate(lowres[None, None], size, mode='trilinear') -> [Dout, H, W] fp32."""
+    _dev(lowres, "saliency_upsample")
+    D, gh, gw = lowres.shape
+    Dout, H, W = (int(v) for v in size)
+    out = torch.empty((Dout, H, W), dtype=torch.float32, device=lowres.device)
+    _check(load().mst_saliency_upsample(ptr(lowres), D, gh, gw, float(scale), Dout, H, W, ptr(out), stream_of(lowres)),
+           "mst_saliency_upsample")
+    return out
 
 
 def liere_rotation(vars_: Sequence[torch.Tensor]) -> torch.Tensor:

@@ -288,6 +288,59 @@ def attention_rollout(vit_maps_full: List[Tensor]) -> Tensor:
     return acc
 
 
+TTA_FLIPS = [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]   # scripts/main_predict.py:148
+
+
+def trilinear_upsample(w: Tensor, size: Tuple[int, int, int]) -> Tensor:
+    """F.interpolate(w, size, mode='trilinear') with align_corners=False (scripts/main_predict.py:163), restated as
+    three separable 1-D linear resamplings of [1,1,D,h,w]: src = max((dst + 0.5) * in/out - 0.5, 0), i0 = floor(src),
+    i1 = min(i0 + 1, in - 1), value = (1 - l) * v[i0] + l * v[i1] (torch UpSampleKernel area_pixel_compute_source_index)."""
+    out = w
+    for axis, n_out in zip((2, 3, 4), size):
+        n_in = out.shape[axis]
+        dst = torch.arange(n_out, dtype=torch.float32)
+        src = ((dst + 0.5) * (n_in / n_out) - 0.5).clamp_(min=0)
+        i0 = src.floor().long().clamp_(max=n_in - 1)
+        i1 = (i0 + 1).clamp_(max=n_in - 1)
+        l1 = (src - i0.float())
+        shape = [1] * 5
+        shape[axis] = n_out
+        l1 = l1.reshape(shape)
+        out = (1 - l1) * out.index_select(axis, i0) + l1 * out.index_select(axis, i1)
+    return out
+
+
+def saliency_lowres(maps: Tensor, slice_attn: Tensor, D: int) -> Tuple[Tensor, Tensor]:
+    """_pred_trans of scripts/main_predict.py:72-105 after the forward (DinoV2 branch, B = 1): head mean of
+    get_attention_maps() -> [1,1,D,g,g] (square grid assumed there: l.90-96) and get_slice_attention() head-mean -> [D]."""
+    w = maps.mean(dim=1)                                    # l.75-76
+    g = int(w.shape[-1] ** 0.5)                             # l.91
+    w = w[:, :g * g].reshape(1, 1, D, g, g)                 # l.94-98
+    ws = slice_attn.mean(dim=1).reshape(D)                  # l.101-102
+    return w, ws
+
+
+def run_pred(sd: SD, source: Tensor, *, use_softmax: bool = True, use_tta: bool = False,
+             src_key_padding_mask: Optional[Tensor] = None, **fw) -> Tuple[Tensor, Tensor, Tensor]:
+    """run_pred(save_attn=True) of scripts/main_predict.py:134-165 for a DinoV2ClassifierSlice on one volume:
+    returns (pred [1,out], weight [1,1,D,H,W], weight_slice [1,1,D,H,W])."""
+    def one(src):
+        o = forward(sd, src, src_key_padding_mask=src_key_padding_mask, keep="cls", **fw)
+        pred = o["logits"].softmax(-1) if use_softmax else o["logits"]
+        D = src.shape[2]
+        w, ws = saliency_lowres(attention_maps(o["vit_maps"][-1], o["slice_map"]), slice_attention(o["slice_map"]), D)
+        return pred, w, ws.reshape(1, 1, D, 1, 1) * torch.ones_like(src)
+    pred, w, ws = one(source)
+    if use_tta:
+        for dims in TTA_FLIPS:
+            p_i, w_i, ws_i = one(torch.flip(source, dims))
+            pred = pred + p_i
+            w = w + torch.flip(w_i, dims)
+            ws = ws + torch.flip(ws_i, dims)
+        pred, w, ws = pred / 8, w / 8, ws / 8
+    return pred, trilinear_upsample(w, tuple(source.shape[2:])), ws
+
+
 def flops_per_volume(D: int, H: int, W: int, E: int = 384, depth: int = 12) -> float:
     """Algorithmic FLOPs of one forward: 2 FLOP per MAC, softmax/LN/GELU not counted."""
     Np = (H // PATCH) * (W // PATCH)

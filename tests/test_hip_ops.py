@@ -371,3 +371,31 @@ def test_liere_rotation_matches_matrix_exp(hip, std):
     assert R.shape == (32, 32)
     assert (R - ref).abs().max() < 1e-6
     assert (R @ R.T - torch.eye(32, dtype=torch.float64)).abs().max() < 1e-6   # a rotation
+
+
+@pytest.mark.parametrize("D,g,size", [(5, 6, (5, 84, 84)), (4, 4, (4, 56, 56)), (3, 7, (6, 50, 37)), (64, 37, (64, 518, 518))])
+def test_saliency_accumulate_and_upsample(hip, D, g, size):
+    """Head mean + flip-back accumulation + trilinear up-sampling (main_predict.py:72-105, 147-165) vs the oracle / torch."""
+    import torch.nn.functional as F
+    from oracle import mst_oracle as O
+    gen = torch.Generator().manual_seed(D * 100 + g)
+    heads, Np = 6, g * g + (3 if g == 7 else 0)               # extra columns past the square grid are ignored (l.94-96)
+    low = torch.empty(D, g, g, device="cuda")
+    ws = torch.empty(D, device="cuda")
+    ref_low = torch.zeros(1, 1, D, g, g)
+    ref_ws = torch.zeros(D)
+    for k, dims in enumerate([()] + O.TTA_FLIPS):
+        maps = torch.rand(D, heads, Np, generator=gen)
+        sa = torch.rand(D, generator=gen)
+        fm = sum(1 << (a - 2) for a in dims)
+        hip.saliency_accumulate(maps.cuda(), sa.cuda(), g, g, fm, low, ws, accumulate=k > 0)
+        w_i = maps.mean(1)[:, :g * g].reshape(1, 1, D, g, g)
+        ref_low += torch.flip(w_i, dims) if dims else w_i
+        ref_ws += torch.flip(sa, (0,)) if 2 in dims else sa
+    assert rel_l2(low.cpu(), ref_low[0, 0]) < 1e-6
+    assert rel_l2(ws.cpu(), ref_ws) < 1e-6
+    out = hip.saliency_upsample(low, size, scale=1.0 / 8)
+    assert tuple(out.shape) == tuple(size)
+    ref = F.interpolate(ref_low / 8, size=size, mode="trilinear")[0, 0]
+    assert rel_l2(out.cpu(), ref) < 2e-6
+    assert rel_l2(out.cpu(), O.trilinear_upsample(ref_low / 8, size)[0, 0]) < 2e-6

@@ -243,3 +243,23 @@ def test_slice_sharded_forward_equals_unsharded_two_ranks_one_gpu():
         same_logits, same_maps, err = ret[r]
         assert same_logits and same_maps, (r, ret[r])
         assert err < TOL["fp16"][0]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16"])
+@pytest.mark.parametrize("name", ["saliency_1x5x84", "saliency_tta_1x4x56x84"])
+def test_run_pred_saliency_volume_matches_reference_fixture(name, mode):
+    """mst.saliency.run_pred == scripts/main_predict.py run_pred(save_attn=True[, use_tta]) on the reference model."""
+    from mst.saliency import run_pred
+    g = load_golden(name)
+    tl, _, tm = TOL[mode]
+    model = build({}, int(g["seed"]), mode)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    pred, weight, ws = run_pred(model, {"source": src, "uid": "x"}, save_attn=True, use_softmax=True, use_tta=bool(g["use_tta"]))
+    assert np.abs(pred.cpu().numpy() - g["pred"]).max() < tl
+    assert tuple(weight.shape) == g["weight"].shape and tuple(ws.shape) == g["weight"].shape
+    assert rel_l2(weight.cpu(), g["weight"]) < tm
+    assert rel_l2(ws[0, 0, :, 0, 0].cpu(), g["weight_slice_per_slice"]) < tm
+    pred2, none_w, none_ws = run_pred(model, {"source": src}, save_attn=False, use_softmax=True, use_tta=bool(g["use_tta"]))
+    assert none_w is None and none_ws is None and torch.allclose(pred2, pred, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        run_pred(model, {"source": torch.cat([src, src])}, save_attn=True)

@@ -156,3 +156,25 @@ def test_attention_rollout_matches_reference():
     roll = O.attention_rollout(out["vit_maps"])
     assert roll.shape == g["attention_cls"].shape
     assert rel_l2(roll, g["attention_cls"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["saliency_1x5x84", "saliency_tta_1x4x56x84"])
+def test_saliency_volume_matches_reference(name):
+    """run_pred(save_attn=True[, use_tta]) of scripts/main_predict.py:134-165 on the reference model's outputs."""
+    g = load_golden(name)
+    sd = synth.synth_state_dict("s", int(g["seed"]))
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    with torch.no_grad():
+        pred, weight, ws = O.run_pred(sd, src, use_softmax=True, use_tta=bool(g["use_tta"]))
+    assert np.abs(pred.numpy() - g["pred"]).max() < 2e-5
+    assert weight.shape == g["weight"].shape
+    assert rel_l2(weight, g["weight"]) < 1e-4
+    assert rel_l2(ws[0, 0, :, 0, 0], g["weight_slice_per_slice"]) < 1e-4
+    assert int(g["weight_slice_is_broadcast"]) == 1 and bool((ws == ws[:, :, :, :1, :1]).all())
+
+
+def test_trilinear_restatement_equals_torch_interpolate():
+    import torch.nn.functional as F
+    w = torch.rand(1, 1, 5, 7, 9, generator=torch.Generator().manual_seed(0))
+    for size in [(5, 98, 126), (9, 14, 20), (5, 7, 9), (3, 100, 4)]:
+        assert (O.trilinear_upsample(w, size) - F.interpolate(w, size=size, mode="trilinear")).abs().max() < 1e-6

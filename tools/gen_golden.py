@@ -279,6 +279,37 @@ def case_rollout(dino, synth, name, shape, seed):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+@torch.no_grad()
+def case_saliency(dino, synth, name, shape, seed, use_tta):
+    """`--get_attention` volume: the REFERENCE model's forward + getters, followed by the torch calls of
+    scripts/main_predict.py run_pred/_pred_trans (l.72-105, 147-165), restated here because the script itself cannot be
+    imported (torchio, monai, torchvision, seaborn absent).  F.interpolate is torch's own."""
+    import torch.nn.functional as F
+    model, sd = build(dino, synth, seed)
+    source = synth.synth_volume(shape, seed + 100)
+
+    def pred_trans(src):                                       # _pred_trans, DinoV2 branch
+        pred = torch.softmax(model(src, save_attn=True), dim=-1)
+        weight = model.get_attention_maps().mean(dim=1)
+        g = int(weight.shape[-1] ** 0.5)
+        weight = weight[:, :g * g].view(1, 1, src.shape[2], g, g)
+        ws = model.get_slice_attention().mean(dim=1).view(1, 1, -1, 1, 1) * torch.ones_like(src)
+        return pred, weight, ws
+
+    pred, weight, ws = pred_trans(source)
+    if use_tta:                                                # run_pred l.147-158
+        for dims in [(2,), (3,), (4,), (2, 3), (2, 4), (3, 4), (2, 3, 4)]:
+            p_i, w_i, ws_i = pred_trans(torch.flip(source, dims))
+            pred, weight, ws = pred + p_i, weight + torch.flip(w_i, dims), ws + torch.flip(ws_i, dims)
+        pred, weight, ws = pred / 8, weight / 8, ws / 8
+    weight = F.interpolate(weight, size=source.shape[2:], mode="trilinear")   # l.163
+    out = {"seed": seed, "shape": np.array(shape), "use_tta": int(use_tta), "pred": np_(pred), "weight": np_(weight),
+           "weight_slice_per_slice": np_(ws[0, 0, :, 0, 0]),
+           "weight_slice_is_broadcast": int(bool((ws == ws[:, :, :, :1, :1]).all()))}
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -307,6 +338,8 @@ def main():
         "s504_1x4x504": lambda: case_end2end(dino, synth, "s504_1x4x504", (1, 1, 4, 504, 504), 7, chunk=4,
                                              plane_subset=[0, 3]),
         "liere": lambda: case_end2end(dino, synth, "liere", (1, 1, 32, 56, 56), 9, rotary="LiRE", mask=[5]),
+        "saliency_1x5x84": lambda: case_saliency(dino, synth, "saliency_1x5x84", (1, 1, 5, 84, 84), 10, False),
+        "saliency_tta_1x4x56x84": lambda: case_saliency(dino, synth, "saliency_tta_1x4x56x84", (1, 1, 4, 56, 56), 11, True),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
     }
     for name, fn in cases.items():
