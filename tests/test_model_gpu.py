@@ -263,3 +263,25 @@ def test_run_pred_saliency_volume_matches_reference_fixture(name, mode):
     assert none_w is None and none_ws is None and torch.allclose(pred2, pred, atol=1e-6)
     with pytest.raises(RuntimeError):
         run_pred(model, {"source": torch.cat([src, src])}, save_attn=True)
+
+
+def test_forward_is_hipgraph_capturable():
+    """Nothing in the C ABI allocates or synchronises, so a forward (workspaces warmed) can be captured into a hipGraph
+    and replayed: same bits as the eager call."""
+    g = load_golden("c1_1x16x224")
+    model = build(CASES["c1_1x16x224"], int(g["seed"]), "fp16")
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100).cuda()
+    with torch.no_grad():
+        eager = model(src)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(src)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(src)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    assert np.abs(out.cpu().numpy() - g["logits"]).max() < TOL["fp16"][0]
