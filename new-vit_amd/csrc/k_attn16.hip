@@ -33,11 +33,15 @@ __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const 
     return u.v;
 }
 
+#ifndef ATTN_WG_WAVES
+#define ATTN_WG_WAVES 4      // query rows per workgroup = 32 x waves (K/V tiles shared by the workgroup); 8 waves measured 1.5 % slower at N = 1370 (6 x 256 rows pad 12 %, 11 x 128 pad 3 %)
+#endif
+constexpr int WGW = ATTN_WG_WAVES, WGT = 64 * WGW, QB = 32 * WGW;
 #ifndef ATTN_WAVES_PER_EU
 #define ATTN_WAVES_PER_EU 4   // 128 VGPRs (5 spilled dwords): 4 waves per SIMD measured 3.4 % faster than 3 at 148
 #endif
 template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                      int N, int heads) {
     typedef typename V8<T>::type vec8;
     __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     // 1-D grid, XCD-aware: the q-blocks of one (sequence, head) get consecutive tile ids on ONE XCD, so its
     // K/V (re-read by every q-block) stay in that XCD's L2 (plain (x,y,z) order deals them over all 8 XCDs:
     // rocprofv3 FETCH_SIZE showed 5.7x the algorithmic bytes).
-    const int nqb = (N + 127) >> 7;
+    const int nqb = (N + QB - 1) / QB;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = tile % nqb, h = (tile / nqb) % heads, seq = tile / (nqb * heads);
     const int E = heads * 64, ld = 3 * E;
@@ -57,8 +61,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     const int h2 = lane >> 5;
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q = lane&31][d = 16*ds + 8*h2 + j]
-    const int q = qb * 128 + wave * 32 + (lane & 31);
-    const bool wave_active = (qb * 128 + wave * 32) < N;
+    const int q = qb * QB + wave * 32 + (lane & 31);
+    const bool wave_active = (qb * QB + wave * 32) < N;
     vec8 bq[4];
     {
         const int qc = q < N ? q : N - 1;
@@ -67,27 +71,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
         for (int ds = 0; ds < 4; ++ds) bq[ds] = *reinterpret_cast<const vec8*>(qp + ds * 16);
     }
 
-    // ---- K/V staging map: thread -> key row r, 16-byte chunks c0, c0+1
-    const int sr = tid >> 2, sc0 = (tid & 3) * 2;
-    const int k_off0 = sr * 128 + ((sc0 ^ ((sr >> 1) & 7)) * 16);
-    const int k_off1 = sr * 128 + (((sc0 + 1) ^ ((sr >> 1) & 7)) * 16);
-    const int v_off0 = sr * 128 + ((sc0 ^ (((sr >> 1) & 1) << 2)) * 16);
-    const int v_off1 = sr * 128 + (((sc0 + 1) ^ (((sr >> 1) & 1) << 2)) * 16);
-    u32x4 rk0, rk1, rv0, rv1;
+    // ---- K/V staging map: 64 key rows x 8 chunks of 16 B per operand; thread -> key row sr, CPT consecutive chunks
+    constexpr int CPT = 512 / WGT;                       // chunks per thread and operand: 2 (4 waves) or 1 (8 waves)
+    const int sr = tid / (8 / CPT), sc0 = (tid % (8 / CPT)) * CPT;
+    int k_off[CPT], v_off[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        k_off[c] = sr * 128 + (((sc0 + c) ^ ((sr >> 1) & 7)) * 16);
+        v_off[c] = sr * 128 + (((sc0 + c) ^ (((sr >> 1) & 1) << 2)) * 16);
+    }
+    u32x4 rk[CPT], rv[CPT];
     auto gload = [&](int t) {
         int key = t * 64 + sr;
         key = key < N ? key : N - 1;
         const T* kp = base + (int64_t)key * ld + E + h * 64 + sc0 * 8;
-        rk0 = *reinterpret_cast<const u32x4*>(kp);
-        rk1 = *reinterpret_cast<const u32x4*>(kp + 8);
-        rv0 = *reinterpret_cast<const u32x4*>(kp + E);
-        rv1 = *reinterpret_cast<const u32x4*>(kp + E + 8);
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            rk[c] = *reinterpret_cast<const u32x4*>(kp + 8 * c);
+            rv[c] = *reinterpret_cast<const u32x4*>(kp + E + 8 * c);
+        }
     };
     auto lstore = [&](int buf) {
-        *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off0) = rk0;
-        *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off1) = rk1;
-        *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off0) = rv0;
-        *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off1) = rv1;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off[c]) = rk[c];
+            *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off[c]) = rv[c];
+        }
     };
 
     // ---- per-lane LDS read offsets
@@ -288,9 +297,9 @@ __global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ q
 
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s) {
     MST_CHECK_ARG(n_seq > 0 && N > 0 && heads > 0, "attention: bad sizes n_seq=%d N=%d heads=%d", n_seq, N, heads);
-    const int64_t nwg = (int64_t)((N + 127) / 128) * heads * n_seq;
+    const int64_t nwg = (int64_t)((N + QB - 1) / QB) * heads * n_seq;
     MST_CHECK_ARG(nwg < (1ll << 31), "attention: grid too large");
-    const dim3 grid((unsigned)nwg), block(256);
+    const dim3 grid((unsigned)nwg), block(WGT);
     if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads);
     else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads);
     else { mst_set_error("attention16: bad dtype %d", dt); return MST_EINVAL; }
