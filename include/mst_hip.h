@@ -89,10 +89,12 @@ int mst_attention_cls_probs(const void* qkv, int dtype, int n_seq, int N, int he
 int mst_attention_probs_full(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim,
                              float* probs, mst_stream_t stream);
 
-/* Bicubic resampling of the patch position grid: vision_transformer.py:179-211
- * (F.interpolate bicubic, antialias off, scale_factor=(g+0.1)/M).  pos_patch fp32 [M*M, E] ->
- * out fp32 [gh*gw, E]. */
-int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset,
+/* Bicubic resampling of the patch position grid: vision_transformer.py:179-211 (F.interpolate bicubic).
+ * offset = interpolate_offset (l.194-202): != 0 -> scale_factor = (g + offset) / M, the vendored default 0.1; 0 -> the
+ * output size is given.  antialias = interpolate_antialias (l.206): torch's anti-aliased bicubic (Keys A = -0.5, support
+ * widened by the down-sampling factor); the hub's register models use offset 0, antialias 1.
+ * pos_patch fp32 [M*M, E] -> out fp32 [gh*gw, E]. */
+int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset, int antialias,
                          float* out, mst_stream_t stream);
 
 /* Gray->RGB + Conv2d(3,E,14,14) + flatten + CLS/register rows + position add:

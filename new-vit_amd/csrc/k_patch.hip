@@ -206,6 +206,41 @@ __global__ void pos_interp_kernel(const float* __restrict__ pos, int M, int E, i
     out[i] = acc;
 }
 
+// Anti-aliased bicubic (interpolate_antialias=True: the hub's register models), torch's separable "aa" resampling
+// (aten UpSampleKernel _compute_indices_weights_aa): support = 2 * max(scale, 1), centre = scale * (dst + 0.5), taps
+// [int(centre - support + 0.5), int(centre + support + 0.5)) clipped to the grid, weights = Keys cubic with A = -0.5
+// (not the -0.75 of the plain bicubic) of (tap - centre + 0.5) / max(scale, 1), normalised to sum 1.
+__device__ __forceinline__ float cubic_aa(float x) {
+    const float A = -0.5f;
+    x = fabsf(x);
+    if (x < 1.0f) return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * A;
+    return 0.0f;
+}
+__global__ void pos_interp_aa_kernel(const float* __restrict__ pos, int M, int E, int gh, int gw, float scale_y,
+                                     float scale_x, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)gh * gw * E) return;
+    const int e = (int)(i % E);
+    const int ox = (int)((i / E) % gw);
+    const int oy = (int)(i / ((int64_t)E * gw));
+    const float supy = 2.0f * fmaxf(scale_y, 1.0f), supx = 2.0f * fmaxf(scale_x, 1.0f);
+    const float invy = 1.0f / fmaxf(scale_y, 1.0f), invx = 1.0f / fmaxf(scale_x, 1.0f);
+    const float cy = scale_y * ((float)oy + 0.5f), cx = scale_x * ((float)ox + 0.5f);
+    const int y0 = max((int)(cy - supy + 0.5f), 0), y1 = min((int)(cy + supy + 0.5f), M);
+    const int x0 = max((int)(cx - supx + 0.5f), 0), x1 = min((int)(cx + supx + 0.5f), M);
+    float sy = 0.f, sx = 0.f;
+    for (int y = y0; y < y1; ++y) sy += cubic_aa(((float)y - cy + 0.5f) * invy);
+    for (int x = x0; x < x1; ++x) sx += cubic_aa(((float)x - cx + 0.5f) * invx);
+    float acc = 0.f;
+    for (int y = y0; y < y1; ++y) {                      // horizontal pass per row, then the vertical weight (torch's order)
+        float row = 0.f;
+        for (int x = x0; x < x1; ++x) row += (cubic_aa(((float)x - cx + 0.5f) * invx) / sx) * pos[((int64_t)y * M + x) * E + e];
+        acc += (cubic_aa(((float)y - cy + 0.5f) * invy) / sy) * row;
+    }
+    out[i] = acc;
+}
+
 template <typename T, typename InT>
 int launch_pe(const void* vol, int n, int H, int W, const void* wp, const float* bias, const float* prefix,
               int n_prefix, const float* pos_patch, int E, float* x, hipStream_t s) {
@@ -259,12 +294,14 @@ int launch_patch_embed(const void* vol, int idt, int n, int H, int W, const void
     return MST_EINVAL;
 }
 
-int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double offset, float* out, hipStream_t s) {
+int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double offset, int antialias, float* out,
+                      hipStream_t s) {
     MST_CHECK_ARG(M > 0 && E > 0 && gh > 0 && gw > 0, "pos_interp: bad sizes");
     // vision_transformer.py:197-199: scale_factor = (g + offset) / M; torch maps dst->src with 1/scale_factor
     const float sy = (float)(1.0 / (((double)gh + offset) / (double)M));
     const float sx = (float)(1.0 / (((double)gw + offset) / (double)M));
     const int64_t tot = (int64_t)gh * gw * E;
-    pos_interp_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(pos, M, E, gh, gw, sy, sx, out);
+    if (antialias) pos_interp_aa_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(pos, M, E, gh, gw, sy, sx, out);
+    else pos_interp_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(pos, M, E, gh, gw, sy, sx, out);
     return mst_check_launch("pos_interp");
 }

@@ -105,10 +105,10 @@ int mst_attention_probs_full(const void* qkv, int dtype, int n_seq, int N, int h
     return launch_probs_full(qkv, dtype, n_seq, N, heads, head_dim, probs, (hipStream_t)stream);
 }
 
-int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset, float* out,
+int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset, int antialias, float* out,
                          mst_stream_t stream) {
     MST_CHECK_ARG(pos_patch && out, "pos_embed_interp: null pointer");
-    return launch_pos_interp(pos_patch, M, E, gh, gw, offset, out, (hipStream_t)stream);
+    return launch_pos_interp(pos_patch, M, E, gh, gw, offset, antialias, out, (hipStream_t)stream);
 }
 
 int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const void* wp, int dtype, const float* bias,

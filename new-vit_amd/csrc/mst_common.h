@@ -164,7 +164,7 @@ int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int 
 int launch_patch_embed(const void* vol, int idt, int n, int H, int W, const void* wp, int dt,
                        const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
                        int E, float* x, hipStream_t s);
-int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double offset, float* out,
+int launch_pos_interp(const float* pos, int M, int E, int gh, int gw, double offset, int antialias, float* out,
                       hipStream_t s);
 int launch_slice_tokens(const float* emb, const float* cls, const float* pos, int B, int D, int E,
                         float* xs, hipStream_t s);

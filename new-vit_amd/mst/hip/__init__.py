@@ -58,7 +58,7 @@ SIGNATURES = {
     "mst_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _i, _vp, _vp]),
     "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
@@ -174,11 +174,12 @@ def attention_probs_full(qkv: torch.Tensor, n_seq: int, N: int, heads: int, head
     return out
 
 
-def pos_embed_interp(pos_patch: torch.Tensor, M: int, gh: int, gw: int, offset: float = 0.1) -> torch.Tensor:
+def pos_embed_interp(pos_patch: torch.Tensor, M: int, gh: int, gw: int, offset: float = 0.1,
+                     antialias: bool = False) -> torch.Tensor:
     _dev(pos_patch, "pos_embed_interp")
     E = pos_patch.shape[-1]
     out = torch.empty((gh * gw, E), dtype=torch.float32, device=pos_patch.device)
-    _check(load().mst_pos_embed_interp(ptr(pos_patch), M, E, gh, gw, offset, ptr(out), stream_of(pos_patch)),
+    _check(load().mst_pos_embed_interp(ptr(pos_patch), M, E, gh, gw, offset, 1 if antialias else 0, ptr(out), stream_of(pos_patch)),
            "mst_pos_embed_interp")
     return out
 

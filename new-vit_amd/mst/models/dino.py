@@ -394,7 +394,11 @@ class DinoV2ClassifierSlice(BasicClassifier):
             else:
                 M = int(math.sqrt(n_stored))
                 assert n_stored == M * M
-                pp = hip.pos_embed_interp(pos[1:].contiguous(), M, gh, gw, 0.1)
+                # Register encoders only exist as the hub's dinov2_vit*14_reg (dino.py:61), which facebookresearch/dinov2
+                # hub/backbones.py builds with interpolate_antialias=True, interpolate_offset=0.0; all others keep the
+                # vendored defaults (vision_transformer.py:66-67)
+                reg = self.encoder.num_register_tokens > 0
+                pp = hip.pos_embed_interp(pos[1:].contiguous(), M, gh, gw, 0.0 if reg else 0.1, antialias=reg)
             self._pos_cache[key] = pp
         return self._pos_cache[key]
 

@@ -70,9 +70,10 @@ def patch_embed(slices: Tensor, w: Tensor, b: Tensor) -> Tensor:
 
 
 def interpolate_pos_encoding(pos_embed: Tensor, npatch: int, w: int, h: int,
-                             offset: float = 0.1) -> Tensor:
-    """vision_transformer.py:179-211 (bicubic, antialias off, scale_factor=(g+0.1)/M).
-    Note the reference passes (w, h) = (x.shape[2], x.shape[3]) = (H, W): l.214,220."""
+                             offset: float = 0.1, antialias: bool = False) -> Tensor:
+    """vision_transformer.py:179-211: bicubic resampling of the stored patch grid.  offset != 0: scale_factor =
+    (g + offset) / M (l.194-199, the vendored default 0.1); offset == 0: output size given (l.200-202).  `antialias` is
+    interpolate_antialias (l.206).  Note the reference passes (w, h) = (x.shape[2], x.shape[3]) = (H, W): l.214,220."""
     N = pos_embed.shape[1] - 1
     if npatch == N and w == h:
         return pos_embed
@@ -82,9 +83,8 @@ def interpolate_pos_encoding(pos_embed: Tensor, npatch: int, w: int, h: int,
     w0, h0 = w // PATCH, h // PATCH
     M = int(math.sqrt(N))
     assert N == M * M
-    sx, sy = float(w0 + offset) / M, float(h0 + offset) / M
-    grid = F.interpolate(patch_pe.reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
-                         antialias=False, scale_factor=(sx, sy))
+    kw = dict(scale_factor=(float(w0 + offset) / M, float(h0 + offset) / M)) if offset else dict(size=(w0, h0))
+    grid = F.interpolate(patch_pe.reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic", antialias=antialias, **kw)
     assert (w0, h0) == tuple(grid.shape[-2:])
     grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
     return torch.cat((cls_pe.unsqueeze(0), grid), dim=1).to(pos_embed.dtype)
@@ -95,8 +95,12 @@ def prepare_tokens(sd: SD, slices: Tensor) -> Tensor:
     n, H, W = slices.shape
     x = patch_embed(slices, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"])
     x = torch.cat((sd["encoder.cls_token"].expand(n, -1, -1), x), dim=1)
-    x = x + interpolate_pos_encoding(sd["encoder.pos_embed"], x.shape[1] - 1, H, W)
     reg = sd.get("encoder.register_tokens")
+    # Registers only exist in the hub's `dinov2_vit*14_reg` models (dino.py:61), which facebookresearch/dinov2
+    # hub/backbones.py (un-vendored: fetched by torch.hub) builds with interpolate_antialias=True, interpolate_offset=0.0;
+    # every other encoder keeps the vendored defaults (vision_transformer.py:66-67: no antialias, offset 0.1).
+    x = x + interpolate_pos_encoding(sd["encoder.pos_embed"], x.shape[1] - 1, H, W,
+                                     offset=0.0 if reg is not None else 0.1, antialias=reg is not None)
     if reg is not None:
         x = torch.cat((x[:, :1], reg.expand(n, -1, -1), x[:, 1:]), dim=1)
     return x

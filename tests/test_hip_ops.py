@@ -399,3 +399,20 @@ def test_saliency_accumulate_and_upsample(hip, D, g, size):
     ref = F.interpolate(ref_low / 8, size=size, mode="trilinear")[0, 0]
     assert rel_l2(out.cpu(), ref) < 2e-6
     assert rel_l2(out.cpu(), O.trilinear_upsample(ref_low / 8, size)[0, 0]) < 2e-6
+
+
+def test_pos_embed_interp_antialias_matches_hub_register_fixture(hip):
+    """interpolate_antialias=True, interpolate_offset=0.0 (the hub's register models) vs the vendored class's own output."""
+    import torch.nn.functional as F
+    g = load_golden("hub_reg")
+    sd = synth.synth_state_dict("s", int(g["seed"]), img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    pe = sd["encoder.pos_embed"][0]
+    for key, gh, gw in (("pos_16x16", 16, 16), ("pos_8x10", 8, 10)):
+        got = hip.pos_embed_interp(pe[1:].contiguous().cuda(), 37, gh, gw, 0.0, antialias=True)
+        assert rel_l2(got.cpu(), g[key][0, 1:]) < 2e-6
+    # up-sampling with antialias (support 2, A = -0.5) and a 1-row target, vs torch
+    small = torch.rand(1, 8, 5, 5)
+    for size in ((9, 7), (1, 3), (5, 5)):
+        ref = F.interpolate(small, size=size, mode="bicubic", antialias=True)[0].permute(1, 2, 0).reshape(-1, 8)
+        got = hip.pos_embed_interp(small[0].permute(1, 2, 0).reshape(25, 8).contiguous().cuda(), 5, size[0], size[1], 0.0, antialias=True)
+        assert rel_l2(got.cpu(), ref) < 2e-6

@@ -285,3 +285,24 @@ def test_forward_is_hipgraph_capturable():
         torch.cuda.synchronize()
     assert torch.equal(out, eager)
     assert np.abs(out.cpu().numpy() - g["logits"]).max() < TOL["fp16"][0]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_hub_register_encoder_matches_reference_class_fixture(mode):
+    """Encoder in the hub's dinov2_vits14_reg configuration (registers, LayerScale, 518 grid, anti-aliased size-based
+    position resampling) vs the vendored reference class built with those arguments (tests/golden/hub_reg.npz)."""
+    from mst.models.dino import _ViT
+    from mst.models import DinoV2ClassifierSlice
+    g = load_golden("hub_reg")
+    sd = synth.synth_state_dict("s", int(g["seed"]), img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode, use_registers=True)
+    model.encoder = _ViT(384, 12, 6, img_size=518, num_register_tokens=4, layerscale=1.0, chunked=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    te = TOL[mode][1]
+    for tag in ("224", "112x140", "518"):
+        shape = tuple(int(v) for v in g[f"shape_{tag}"])
+        x = synth.synth_volume((1, 1) + shape, int(g["seed"]) + 100)[0, 0].cuda()
+        with torch.no_grad():
+            emb, _, _ = model.encode_slices(x)
+        assert rel_l2(emb.cpu(), g[f"emb_{tag}"]) < te, tag

@@ -178,3 +178,18 @@ def test_trilinear_restatement_equals_torch_interpolate():
     w = torch.rand(1, 1, 5, 7, 9, generator=torch.Generator().manual_seed(0))
     for size in [(5, 98, 126), (9, 14, 20), (5, 7, 9), (3, 100, 4)]:
         assert (O.trilinear_upsample(w, size) - F.interpolate(w, size=size, mode="trilinear")).abs().max() < 1e-6
+
+
+def test_hub_register_encoder_matches_reference_class():
+    """Encoder configured as torch.hub's dinov2_vits14_reg (registers, LayerScale, anti-aliased size-based pos resampling)."""
+    g = load_golden("hub_reg")
+    sd = synth.synth_state_dict("s", int(g["seed"]), img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    pe = sd["encoder.pos_embed"]
+    assert rel_l2(O.interpolate_pos_encoding(pe, 256, 224, 224, offset=0.0, antialias=True), g["pos_16x16"]) < 1e-6
+    assert rel_l2(O.interpolate_pos_encoding(pe, 80, 112, 140, offset=0.0, antialias=True), g["pos_8x10"]) < 1e-6
+    for tag in ("224", "112x140", "518"):
+        shape = tuple(int(v) for v in g[f"shape_{tag}"])
+        x = synth.synth_volume((1, 1) + shape, int(g["seed"]) + 100)[0, 0]
+        with torch.no_grad():
+            emb, _ = O.vit_encode(sd, x)
+        assert np.abs(emb.numpy() - g[f"emb_{tag}"]).max() < 5e-5, tag

@@ -310,6 +310,29 @@ def case_saliency(dino, synth, name, shape, seed, use_tta):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+@torch.no_grad()
+def case_hub_reg(synth, name, seed):
+    """The encoder as torch.hub's dinov2_vits14_reg configures the vendored class (facebookresearch/dinov2 hub/backbones.py:
+    img_size 518, init_values 1.0, block_chunks 0, 4 register tokens, interpolate_antialias=True, interpolate_offset=0.0),
+    filled with synthetic weights: registers + LayerScale + anti-aliased size-based position resampling."""
+    vt = importlib.import_module("refmst.models.extern.dinov2.vision_transformer")
+    enc = vt.vit_small(patch_size=14, img_size=518, init_values=1.0, block_chunks=0, num_register_tokens=4,
+                       interpolate_antialias=True, interpolate_offset=0.0).eval()
+    sd = synth.synth_state_dict("s", seed, img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    missing, unexpected = enc.load_state_dict(enc_sd, strict=False)
+    assert not unexpected and all("mask_token" in m for m in missing), (missing, unexpected)
+    out = {"seed": seed}
+    for tag, shape in (("224", (3, 224, 224)), ("112x140", (2, 112, 140)), ("518", (1, 518, 518))):
+        x = synth.synth_volume((1, 1) + shape, seed + 100)[0, 0]                 # [n, H, W] slices
+        out[f"emb_{tag}"] = np_(enc(x[:, None].repeat(1, 3, 1, 1)))
+        out[f"shape_{tag}"] = np.array(shape)
+    out["pos_16x16"] = np_(enc.interpolate_pos_encoding(torch.zeros(1, 257, 384), 224, 224))
+    out["pos_8x10"] = np_(enc.interpolate_pos_encoding(torch.zeros(1, 81, 384), 112, 140))
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -340,6 +363,7 @@ def main():
         "liere": lambda: case_end2end(dino, synth, "liere", (1, 1, 32, 56, 56), 9, rotary="LiRE", mask=[5]),
         "saliency_1x5x84": lambda: case_saliency(dino, synth, "saliency_1x5x84", (1, 1, 5, 84, 84), 10, False),
         "saliency_tta_1x4x56x84": lambda: case_saliency(dino, synth, "saliency_tta_1x4x56x84", (1, 1, 4, 56, 56), 11, True),
+        "hub_reg": lambda: case_hub_reg(synth, "hub_reg", 12),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
     }
     for name, fn in cases.items():
