@@ -235,11 +235,12 @@ def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
 def forward(sd: SD, source: Tensor, *, model_size: str = "s", slice_fusion_type: str = "transformer",
             src_key_padding_mask: Optional[Tensor] = None, rotary: Optional[str] = None,
             without_linear: bool = False, keep: str = "none") -> Dict[str, Tensor]:
-    """DinoV2ClassifierSlice.forward (dino.py:110-167).  source = [B,1,D,H,W].
+    """DinoV2ClassifierSlice.forward (dino.py:110-167).  source = [B,C,D,H,W]; channels become extra slices, channel
+    fastest ('b c d h w -> (b d c) h w', l.125).
 
     Returns dict(logits|features, emb [B*D,E], vit_maps list, slice_map [B,12,L,L] or None)."""
     B, C, D, H, W = source.shape
-    emb, maps = vit_encode(sd, source.reshape(B * C * D, H, W), model_size, keep)   # l.125-131
+    emb, maps = vit_encode(sd, source.permute(0, 2, 1, 3, 4).reshape(B * D * C, H, W), model_size, keep)   # l.125-131
     x = emb
     if "bottleneck.weight" in sd:                                                    # l.134-135
         x = F.linear(x, sd["bottleneck.weight"], sd["bottleneck.bias"])

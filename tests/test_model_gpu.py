@@ -306,3 +306,20 @@ def test_hub_register_encoder_matches_reference_class_fixture(mode):
         with torch.no_grad():
             emb, _, _ = model.encode_slices(x)
         assert rel_l2(emb.cpu(), g[f"emb_{tag}"]) < te, tag
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_multichannel_input_matches_reference_fixture(mode):
+    """C = 3 volumes: channels become extra slices, channel fastest (dino.py:125); mask over D*C positions."""
+    g = load_golden("multichannel")
+    tl, _, tm = TOL[mode]
+    model = build({}, int(g["seed"]), mode)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    with torch.no_grad():
+        logits = model(src, src_key_padding_mask=mask, save_attn=True)
+        maps = model.get_attention_maps()
+        sa = model.get_slice_attention()
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
+    assert rel_l2(maps.cpu(), g["attention_maps"]) < tm
+    assert rel_l2(sa.cpu(), g["slice_attention"]) < tm

@@ -193,3 +193,18 @@ def test_hub_register_encoder_matches_reference_class():
         with torch.no_grad():
             emb, _ = O.vit_encode(sd, x)
         assert np.abs(emb.numpy() - g[f"emb_{tag}"]).max() < 5e-5, tag
+
+
+def test_multichannel_input_matches_reference():
+    """C = 3: 'b c d h w -> (b d c) h w' (dino.py:125) and a key-padding mask over the D*C pseudo-slices."""
+    g = load_golden("multichannel")
+    sd = synth.synth_state_dict("s", int(g["seed"]))
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    with torch.no_grad():
+        out = O.forward(sd, src, src_key_padding_mask=mask, keep="cls")
+        feat = O.forward(sd, src, src_key_padding_mask=mask, without_linear=True)
+    assert np.abs(out["logits"].numpy() - g["logits"]).max() < 2e-5
+    assert np.abs(feat["features"].numpy() - g["features"]).max() < 5e-5
+    assert rel_l2(O.slice_attention(out["slice_map"]), g["slice_attention"]) < 1e-4
+    assert rel_l2(O.attention_maps(out["vit_maps"][-1], out["slice_map"]), g["attention_maps"]) < 1e-4

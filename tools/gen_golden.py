@@ -311,6 +311,24 @@ def case_saliency(dino, synth, name, shape, seed, use_tta):
 
 
 @torch.no_grad()
+def case_multichannel(dino, synth, name, shape, seed):
+    """C = 3 input: channels become extra slices, channel fastest (dino.py:125); key-padding mask over D*C positions."""
+    model, sd = build(dino, synth, seed)
+    src = synth.synth_volume(shape, seed + 100)
+    B, C, D, H, W = shape
+    m = torch.zeros(B, D * C, dtype=torch.bool)
+    m[1, -2:] = True
+    out = {"seed": seed, "shape": np.array(shape), "src_key_padding_mask": m.numpy()}
+    out["logits"] = np_(model(src, src_key_padding_mask=m, save_attn=True))
+    out["slice_attention"] = np_(model.get_slice_attention())
+    model(src, src_key_padding_mask=m, save_attn=True)
+    out["attention_maps"] = np_(model.get_attention_maps())
+    out["features"] = np_(model(src, src_key_padding_mask=m, without_linear=True))
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+@torch.no_grad()
 def case_hub_reg(synth, name, seed):
     """The encoder as torch.hub's dinov2_vits14_reg configures the vendored class (facebookresearch/dinov2 hub/backbones.py:
     img_size 518, init_values 1.0, block_chunks 0, 4 register tokens, interpolate_antialias=True, interpolate_offset=0.0),
@@ -363,6 +381,7 @@ def main():
         "liere": lambda: case_end2end(dino, synth, "liere", (1, 1, 32, 56, 56), 9, rotary="LiRE", mask=[5]),
         "saliency_1x5x84": lambda: case_saliency(dino, synth, "saliency_1x5x84", (1, 1, 5, 84, 84), 10, False),
         "saliency_tta_1x4x56x84": lambda: case_saliency(dino, synth, "saliency_tta_1x4x56x84", (1, 1, 4, 56, 56), 11, True),
+        "multichannel": lambda: case_multichannel(dino, synth, "multichannel", (2, 3, 2, 56, 70), 13),
         "hub_reg": lambda: case_hub_reg(synth, "hub_reg", 12),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
     }
