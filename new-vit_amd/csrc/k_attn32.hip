@@ -163,11 +163,8 @@ int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hip
     const int64_t nwg = (int64_t)((N + 127) / 128) * heads * n_seq;
     MST_CHECK_ARG(nwg < (1ll << 31), "attention32: grid too large");
     const size_t sh = (size_t)4 * TILE_F * sizeof(float);  // 66,560 B
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    static mst_lds_once lds_once;
+    mst_allow_lds((const void*)attn32_kernel, (int)sh, &lds_once);
     attn32_kernel<<<dim3((unsigned)nwg), dim3(256), sh, s>>>(qkv, out, N, heads);
     return mst_check_launch("attention32");
 }

@@ -162,12 +162,9 @@ template <typename T, int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
              int64_t ldc, int64_t M, int N, int K, const float* gamma, float col_scale, int scale_cols,
              hipStream_t s) {
-    static bool attr_set = false;
+    static mst_lds_once lds_once;
     auto kern = gemm16_kernel<T, EPI, OutT>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-        attr_set = true;
-    }
+    mst_allow_lds((const void*)kern, 4 * TILE_BYTES, &lds_once);
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int nwg = tiles_m * tiles_n;
     kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc,

@@ -216,12 +216,9 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
 template <typename T, int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
              int N, int K, const float* gamma, float cs, int sc, hipStream_t s) {
-    static bool attr_set = false;
+    static mst_lds_once lds_once;
     auto kern = gemm16_mid_kernel<T, EPI, OutT>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
     int nblk = ntiles < NBLK ? ((ntiles + 7) / 8) * 8 : NBLK;

@@ -391,12 +391,9 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
 template <typename T>
 int launch_t(float* x, void* xn_out, const void* wpack, const float* b1f, const float* b2, int64_t M, float eps,
              hipStream_t s) {
-    static bool attr_set = false;
+    static mst_lds_once lds_once;
     auto kern = mlp16_kernel<T>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int ntiles = (int)((M + 127) / 128);
     const int nblk = ntiles < 256 ? ntiles : 256;
     kern<<<dim3(nblk), dim3(512), LDS_BYTES, s>>>(x, (T*)xn_out, (const char*)wpack, b1f, b2, nullptr, (int)M, ntiles, eps);

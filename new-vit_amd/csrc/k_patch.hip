@@ -252,11 +252,8 @@ int launch_pe(const void* vol, int n, int H, int W, const void* wp, const float*
     constexpr int BMP = 32 * TileW<T>::v, BNP = BMP;
     constexpr int sh = 2 * BMP * RowBytes<T>::v;
     auto kern = patch_embed_kernel<T, InT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh);
-        attr_set = true;
-    }
+    static mst_lds_once lds_once;
+    mst_allow_lds((const void*)kern, sh, &lds_once);
     const dim3 grid((unsigned)((total + BMP - 1) / BMP), E / BNP);
     kern<<<grid, dim3(256), sh, s>>>((const InT*)vol, H, W, gw, Np, total, (const T*)wp, bias, pos_patch, n_prefix, E, x);
     int rc = mst_check_launch("patch_embed");

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "mst_common.h"
 
 static thread_local char g_err[512] = "";
@@ -26,9 +29,17 @@ int mst_check_launch(const char* what) {
     return MST_OK;
 }
 
+void mst_allow_lds(const void* kernel, int bytes, mst_lds_once* slot) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;   // unknown / far device: always set
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev != 63 && (slot->done_mask >> dev) & 1ull) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    slot->done_mask |= 1ull << dev;
+}
+
 // ---- optional per-kernel event timing (bench only) -------------------------------------------------
-#include <mutex>
-#include <vector>
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;

@@ -135,6 +135,10 @@ void mst_set_error(const char* fmt, ...);
         }                                       \
     } while (0)
 int mst_check_launch(const char* what);
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and a process may drive
+// several GPUs.  Thread-safe; `slot` is a static per-kernel token owned by the call site.
+struct mst_lds_once { unsigned long long done_mask = 0; };
+void mst_allow_lds(const void* kernel, int bytes, mst_lds_once* slot);
 
 // kernel launchers shared between translation units (all asynchronous on `s`)
 int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
