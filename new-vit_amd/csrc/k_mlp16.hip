@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void mlp16_kernel(float* __restrict__ x, T* __
         const unsigned u = (((unsigned)blockIdx.x >> 3) + 5u * ((unsigned)blockIdx.x & 7u)) & 15u;   // 0..15
         const unsigned long long delay = (unsigned long long)TILE_CYCLES * ((my_tiles > min_tiles ? 0u : 16u) + u) / 32u;
         const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+        for (int it = 0; it < 512 && __builtin_readcyclecounter() - t0 < delay; ++it) __builtin_amdgcn_s_sleep(32);   // bounded: every wave leaves
     }
 
     // The two roles run two separate step loops (same number of s_barriers: one per step 0..last), so the
