@@ -323,3 +323,26 @@ def test_multichannel_input_matches_reference_fixture(mode):
     assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
     assert rel_l2(maps.cpu(), g["attention_maps"]) < tm
     assert rel_l2(sa.cpu(), g["slice_attention"]) < tm
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_massive_activation_channels_against_oracle(mode):
+    """Pretrained DINOv2 carries a few residual-stream channels with magnitudes in the hundreds.  Emulate them (two fc2
+    output channels and their bias scaled x200 in block 3) and check that nothing in the 16-bit paths saturates: the
+    LayerNorms see rows dominated by two outliers, the residual stream stays fp32."""
+    from oracle import mst_oracle as O
+    sd = synth.synth_state_dict("s", 31)
+    pre = "encoder.blocks.0.3.mlp.fc2."
+    for ch in (7, 200):
+        sd[pre + "weight"][ch] *= 200.0
+        sd[pre + "bias"][ch] = 150.0
+    from mst.models import DinoV2ClassifierSlice
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    src = synth.synth_volume((1, 1, 3, 112, 112), 77)
+    with torch.no_grad():
+        emb, _, _ = model.encode_slices(src.cuda().reshape(3, 112, 112))
+        ref, _ = O.vit_encode(sd, src.reshape(3, 112, 112))
+    assert bool(torch.isfinite(emb).all())
+    assert rel_l2(emb.cpu(), ref) < {"fp32": 2e-4, "fp16": 6e-3, "bf16": 6e-2}[mode]
