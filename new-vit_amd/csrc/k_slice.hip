@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void plane_readout_kernel(const float* __restr
     const float w = sa ? sa[n] : 0.f;
     const int64_t o = ((int64_t)n * heads + h) * Np;
     for (int p = tid; p < Np; p += 256) {
-        const float v = (p == 0) ? 0.f : row[p] * inv;
+        const float v = ((p == 0) ? 0.f : row[p]) * inv;   // a one-patch grid gives 0 * inf = NaN, like the reference's 0 / 0
         if (plane) plane[o + p] = v;
         if (maps) maps[o + p] = w * v;
     }

@@ -346,3 +346,30 @@ def test_massive_activation_channels_against_oracle(mode):
         ref, _ = O.vit_encode(sd, src.reshape(3, 112, 112))
     assert bool(torch.isfinite(emb).all())
     assert rel_l2(emb.cpu(), ref) < {"fp32": 2e-4, "fp16": 6e-3, "bf16": 6e-2}[mode]
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 14, 14), (2, 1, 256, 28, 28), (1, 1, 2, 14, 518), (3, 1, 5, 98, 14)])
+def test_extreme_shapes_against_oracle(shape):
+    """One slice of one patch (N = 2, L = 2); the maximum slice count of the slice position table (L = 257); one-patch-high
+    and one-patch-wide grids (bicubic resampling to a 1 x 37 / 7 x 1 grid)."""
+    from oracle import mst_oracle as O
+    sd = synth.synth_state_dict("s", 5, use_slice_pos_emb=True)
+    from mst.models import DinoV2ClassifierSlice
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp32", use_slice_pos_emb=True)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    src = synth.synth_volume(shape, 3)
+    B, D = shape[0], shape[2]
+    mask = torch.zeros(B, D, dtype=torch.bool)
+    if D > 2:
+        mask[0, -2:] = True
+    with torch.no_grad():
+        logits = model(src, src_key_padding_mask=mask, save_attn=True)
+        maps = model.get_attention_maps()
+        ref = O.forward(sd, src, src_key_padding_mask=mask, keep="cls")
+    assert np.abs(logits.cpu().numpy() - ref["logits"].numpy()).max() < 1e-4
+    ref_maps = O.attention_maps(ref["vit_maps"][-1], ref["slice_map"])
+    finite = torch.isfinite(ref_maps)
+    assert bool((torch.isfinite(maps.cpu()) == finite).all())       # N = 2: the only patch is zeroed -> 0/0 in the reference too
+    if bool(finite.all()):
+        assert rel_l2(maps.cpu(), ref_maps) < 1e-3
