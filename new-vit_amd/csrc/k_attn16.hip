@@ -5,7 +5,7 @@
 // Workgroup = 4 waves x 32 query rows; K/V tiles of 64 keys are shared through a 2-deep LDS ring,
 // register-staged (global loads for tile t+1 are issued before the MFMAs of tile t and written to
 // LDS after them: one barrier per tile).  Per wave and tile:
-//   S^T[key][q] = K . Q^T   (v_mfma_f32_32x32x16, K rows via ds_read_b128 from an XOR-swizzled
+//   S^T[key][q] = K . Q^T   (v_mfma_f32_32x32x16, K rows via ds_read_b128 from a 144-byte-row
 //                            image, Q fragments resident in registers)  -> the query sits on the
 //                            lane, so the row max / sum are in-lane plus ONE cross-half shuffle;
 //   O^T[d][q]  += V^T . P^T  the S^T accumulator registers, converted to 16-bit in place, ARE the
@@ -22,7 +22,11 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int KV_TILE_BYTES = 64 * 128;  // 64 keys x 64 dims x 2 B
+constexpr int KV_TILE_BYTES = 64 * 128;  // V tile: 64 keys x 64 dims x 2 B
+// K rows are PADDED to 144 B instead of XOR-swizzled: 36-dword rows put the 16 lanes of a ds_read_b128 group on 16 distinct
+// 4-bank groups (conflict-free), and every fragment address of a tile becomes ONE lane offset plus an immediate (the
+// XOR made each of the 8 reads its own lane function: ~25 address VALU ops per tile in an issue-bound loop).
+constexpr int K_ROW = 144, K_TILE_BYTES = 64 * K_ROW;
 
 template <typename T>
 __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const char* p_hi) {
@@ -44,9 +48,9 @@ template <typename T>
 __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                      int N, int heads) {
     typedef typename V8<T>::type vec8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * KV_TILE_BYTES];
     char* const Ks = smem;
-    char* const Vs = smem + 2 * KV_TILE_BYTES;
+    char* const Vs = smem + 2 * K_TILE_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     int k_off[CPT], v_off[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-        k_off[c] = sr * 128 + (((sc0 + c) ^ ((sr >> 1) & 7)) * 16);
+        k_off[c] = sr * K_ROW + (sc0 + c) * 16;
         v_off[c] = sr * 128 + (((sc0 + c) ^ (((sr >> 1) & 1) << 2)) * 16);
     }
     u32x4 rk[CPT], rv[CPT];
@@ -94,15 +98,15 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            *reinterpret_cast<u32x4*>(Ks + buf * KV_TILE_BYTES + k_off[c]) = rk[c];
+            *reinterpret_cast<u32x4*>(Ks + buf * K_TILE_BYTES + k_off[c]) = rk[c];
             *reinterpret_cast<u32x4*>(Vs + buf * KV_TILE_BYTES + v_off[c]) = rv[c];
         }
     };
 
     // ---- per-lane LDS read offsets
-    // K (ds_read_b128): row = kb*32 + (lane&31), chunk = 2*ds + h2, slot = chunk ^ ((row>>1)&7)
+    // K (ds_read_b128): row = kb*32 + (lane&31), 16-byte chunk 2*ds + h2 of a 144-byte row
     const int krow = lane & 31;
-    const int ksw = (krow >> 1) & 7;  // kb*32 does not change ((row>>1)&7)
+    const int k_lane_off = krow * K_ROW + h2 * 16;       // + kb*32*K_ROW + ds*32: immediates
     // V (ds_read_b64_tr_b16): 16-lane group g: rows key0 + (i>>2), key0 = ks*16 + 4*h2,
     // columns db*32 + 16*(g&1) + 4*(i&3) .. +3  ->  chunk = db*4 + (g&1)*2 + ((i&3)>>1), +8 B if i odd
     const int vi = lane & 15;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
         const int buf = t & 1;
         if (t + 1 < nt) gload(t + 1);
         if (wave_active) {
-            const char* Kb = Ks + buf * KV_TILE_BYTES;
+            const char* Kb = Ks + buf * K_TILE_BYTES;
             const char* Vb = Vs + buf * KV_TILE_BYTES;
             f32x16 s[2];
 #pragma unroll
@@ -137,8 +141,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
                 for (int ds = 0; ds < 4; ++ds) {
-                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + (kb * 32 + krow) * 128 +
-                                                                  (((2 * ds + h2) ^ ksw) * 16));
+                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
                     s[kb] = mfma32(a, bq[ds], s[kb]);
                 }
             }
