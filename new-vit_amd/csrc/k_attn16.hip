@@ -6,7 +6,8 @@
 // register-staged (global loads for tile t+1 are issued before the MFMAs of tile t and written to
 // LDS after them: one barrier per tile).  Per wave and tile:
 //   S^T[key][q] = K . Q^T   (v_mfma_f32_32x32x16, K rows via ds_read_b128 from a 144-byte-row
-//                            image, Q fragments resident in registers)  -> the query sits on the
+//                            image, Q fragments resident in registers, pre-multiplied by log2 e; the chain starts with one
+//                            extra MFMA that puts -r[q], the per-query softmax reference point, into every key row)  -> the query sits on the
 //                            lane, so the row max / sum are in-lane plus ONE cross-half shuffle;
 //   O^T[d][q]  += V^T . P^T  the S^T accumulator registers, converted to 16-bit in place, ARE the
 //                            B operand (k order 16s+8(j>>2)+4h+(j&3)); the matching V^T fragment is
@@ -37,6 +38,9 @@ __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const 
     return u.v;
 }
 
+#ifndef ATTN_NO_CREF
+#define ATTN_CREF 1        // reference point subtracted by the matrix pipe (measured -5 % on the bench shape); -DATTN_NO_CREF restores the fma form
+#endif
 #ifndef ATTN_WG_WAVES
 #define ATTN_WG_WAVES 4      // query rows per workgroup = 32 x waves (K/V tiles shared by the workgroup); 8 waves measured 1.5 % slower at N = 1370 (6 x 256 rows pad 12 %, 11 x 128 pad 3 %)
 #endif
@@ -46,7 +50,7 @@ constexpr int WGW = ATTN_WG_WAVES, WGT = 64 * WGW, QB = 32 * WGW;
 #endif
 template <typename T>
 __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                     int N, int heads) {
+                                                     int N, int heads, int log2q) {
     typedef typename V8<T>::type vec8;
     __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * KV_TILE_BYTES];
     char* const Ks = smem;
@@ -118,7 +122,27 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     f32x16 oT[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[0][r] = oT[1][r] = 0.f;
+#ifdef ATTN_CREF
+    // Scores in the log2 domain (Q fragments pre-multiplied by log2 e) and RELATIVE to a per-query reference point r that the
+    // matrix pipe subtracts: the chain of a score tile starts with one extra MFMA  ones[key][k] . (-r)[k][q]  instead of a
+    // zero accumulator, so p = exp2(s) needs no per-element fma / sub in this issue-bound loop.  Softmax is invariant to the
+    // reference point; r only has to stay within 2^RT of the running maximum, so it is a 16-bit value (exactly representable
+    // as an MFMA operand) that moves only when a tile's maximum exceeds it by more than RT.
+    if (!log2q) {                                        // stand-alone contract: q carries head_dim^-0.5 only
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[ds][j] = (T)((float)bq[ds][j] * LOG2E);
+    }
+    vec8 kone, qneg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kone[j] = qneg[j] = (T)0.f;
+    if (h2 == 0) kone[0] = (T)1.f;
+    float r_ref = 0.f, l_run = 0.f;
+    constexpr float RT = 8.0f;
+#else
     float m_run = -INFINITY, l_run = 0.f;
+#endif
 
     const int nt = (N + 63) >> 6;
     gload(0);
@@ -135,6 +159,59 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             const char* Kb = Ks + buf * K_TILE_BYTES;
             const char* Vb = Vs + buf * KV_TILE_BYTES;
             f32x16 s[2];
+#ifdef ATTN_CREF
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = mfma32(kone, qneg, zero16);      // -r[q] in every key row
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds) {
+                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
+                    s[kb] = mfma32(a, bq[ds], s[kb]);
+                }
+            }
+            if constexpr (MASK) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                        if (key >= N) s[kb][r] = -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (t == 0 || !__all(mx <= RT)) {            // rare after the first tiles: move the reference point
+                const bool mv = (t == 0) || (mx > RT);
+                const float r_new = mv ? (float)(T)(r_ref + mx) : r_ref;   // 16-bit representable
+                const float delta = r_new - r_ref;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                r_ref = r_new;
+                if (h2 == 0) qneg[0] = (T)(-r_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    oT[0][r] *= alpha;
+                    oT[1][r] *= alpha;
+                    s[0][r] -= delta;
+                    s[1][r] -= delta;
+                }
+            }
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                    s[kb][r] = p;
+                    lsum += p;
+                }
+            l_run += lsum;
+#else
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -181,6 +258,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                     oT[1][r] *= alpha;
                 }
             }
+#endif
             vec8 pf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -225,7 +303,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 // ---- CLS-row probabilities: softmax_j(q_0 . k_j) per (sequence, head) -> probs[seq][h][N] fp32.
 template <typename T>
 __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qkv, float* __restrict__ probs,
-                                                        int N, int heads, int hd) {
+                                                        int N, int heads, int hd, int log2q) {
     extern __shared__ float sm[];  // [hd] q0 | [N] scores | [8] reduce
     float* q0 = sm;
     float* sc = sm + hd;
@@ -249,7 +327,7 @@ __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qk
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
     for (int j = tid; j < N; j += 256) {
-        const float p = __expf(sc[j] - mx);
+        const float p = log2q ? exp2f(sc[j] - mx) : __expf(sc[j] - mx);   // log2q: the scores are already in the log2 domain
         sc[j] = p;
         sum += p;
     }
@@ -264,7 +342,7 @@ __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qk
 // ---- full probabilities (API parity for the `attention_maps` list / rollout): one wave per query.
 template <typename T>
 __global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ qkv, float* __restrict__ probs,
-                                                         int N, int heads, int hd) {
+                                                         int N, int heads, int hd, int log2q) {
     extern __shared__ float sm[];  // per wave: [hd] q | [N] scores
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* qv = sm + wave * (hd + N);
@@ -287,7 +365,7 @@ __global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ q
     mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < N; j += 64) {
-        const float p = __expf(sc[j] - mx);
+        const float p = log2q ? exp2f(sc[j] - mx) : __expf(sc[j] - mx);   // log2q: the scores are already in the log2 domain
         sc[j] = p;
         sum += p;
     }
@@ -298,35 +376,35 @@ __global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ q
 
 }  // namespace
 
-int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s) {
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s) {
     MST_CHECK_ARG(n_seq > 0 && N > 0 && heads > 0, "attention: bad sizes n_seq=%d N=%d heads=%d", n_seq, N, heads);
     const int64_t nwg = (int64_t)((N + QB - 1) / QB) * heads * n_seq;
     MST_CHECK_ARG(nwg < (1ll << 31), "attention: grid too large");
     const dim3 grid((unsigned)nwg), block(WGT);
-    if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads);
-    else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads);
+    if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads, log2q);
+    else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads, log2q);
     else { mst_set_error("attention16: bad dtype %d", dt); return MST_EINVAL; }
     return mst_check_launch("attention16");
 }
 
-int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, hipStream_t s) {
+int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q, hipStream_t s) {
     MST_CHECK_ARG(N > 0 && N <= 12000 && hd > 0 && hd <= 256, "cls_probs: N=%d hd=%d unsupported", N, hd);
     const dim3 grid(heads, n_seq), block(256);
     const size_t sh = (size_t)(hd + N + 8) * sizeof(float);
-    if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd);
-    else if (dt == MST_F16) cls_probs_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd);
-    else if (dt == MST_F32) cls_probs_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd);
+    if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd, log2q);
+    else if (dt == MST_F16) cls_probs_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd, log2q);
+    else if (dt == MST_F32) cls_probs_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd, log2q);
     else { mst_set_error("cls_probs: bad dtype %d", dt); return MST_EINVAL; }
     return mst_check_launch("cls_probs");
 }
 
-int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, hipStream_t s) {
+int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q, hipStream_t s) {
     MST_CHECK_ARG(N > 0 && N <= 3800 && hd > 0 && hd <= 256, "probs_full: N=%d hd=%d unsupported", N, hd);
     const dim3 grid((N + 3) / 4, heads, n_seq), block(256);
     const size_t sh = (size_t)4 * (hd + N) * sizeof(float);
-    if (dt == MST_BF16) probs_full_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd);
-    else if (dt == MST_F16) probs_full_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd);
-    else if (dt == MST_F32) probs_full_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd);
+    if (dt == MST_BF16) probs_full_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd, log2q);
+    else if (dt == MST_F16) probs_full_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd, log2q);
+    else if (dt == MST_F32) probs_full_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd, log2q);
     else { mst_set_error("probs_full: bad dtype %d", dt); return MST_EINVAL; }
     return mst_check_launch("probs_full");
 }

@@ -101,19 +101,19 @@ int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int h
     MST_CHECK_ARG(qkv && out, "attention: null pointer");
     MST_CHECK_ARG(head_dim == 64, "attention: head_dim=%d unsupported (64)", head_dim);
     if (dtype == MST_F32) return launch_attn32((const float*)qkv, n_seq, N, heads, (float*)out, (hipStream_t)stream);
-    return launch_attn16(qkv, dtype, n_seq, N, heads, out, (hipStream_t)stream);
+    return launch_attn16(qkv, dtype, n_seq, N, heads, out, 0, (hipStream_t)stream);
 }
 
 int mst_attention_cls_probs(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, float* probs,
                             mst_stream_t stream) {
     MST_CHECK_ARG(qkv && probs, "cls_probs: null pointer");
-    return launch_cls_probs(qkv, dtype, n_seq, N, heads, head_dim, probs, (hipStream_t)stream);
+    return launch_cls_probs(qkv, dtype, n_seq, N, heads, head_dim, probs, 0, (hipStream_t)stream);
 }
 
 int mst_attention_probs_full(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, float* probs,
                              mst_stream_t stream) {
     MST_CHECK_ARG(qkv && probs, "probs_full: null pointer");
-    return launch_probs_full(qkv, dtype, n_seq, N, heads, head_dim, probs, (hipStream_t)stream);
+    return launch_probs_full(qkv, dtype, n_seq, N, heads, head_dim, probs, 0, (hipStream_t)stream);
 }
 
 int mst_pos_embed_interp(const float* pos_patch, int M, int E, int gh, int gw, double offset, int antialias, float* out,
@@ -185,7 +185,10 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     void* xn = (char*)ws + off_xn;
     void* big = (char*)ws + off_big;
     const size_t in_sz = dt_size(in_dtype);
-    const float qscale = 0.125f;  // head_dim^-0.5, head_dim = 64 (attention.py:48)
+    // head_dim^-0.5, head_dim = 64 (attention.py:48); the 16-bit attention kernels work in the log2 domain, so log2(e) rides
+    // on the same fp32 multiply of the QKV epilogue (one rounding of q, not two)
+    const int log2q = dt != MST_F32;
+    const float qscale = log2q ? 0.125f * 1.4426950408889634f : 0.125f;
 
 #define RUN(call)              \
     do {                       \
@@ -223,10 +226,11 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             }
             const int li = l - (w->depth - n_layers_probs);
             if (cls_probs && li >= 0)
-                RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, s));
+                RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, log2q, s));
             if (full_probs && li >= 0)
-                RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, s));
-            RUNK(MST_K_ATTENTION, mst_attention(big, dt, c, N, heads, 64, xn, s));
+                RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, log2q, s));
+            if (dt == MST_F32) RUNK(MST_K_ATTENTION, launch_attn32((const float*)big, c, N, heads, (float*)xn, s));
+            else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
             // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
             if (fused) {

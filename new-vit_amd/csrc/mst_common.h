@@ -159,11 +159,13 @@ int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, cons
                   float col_scale, int scale_cols, hipStream_t s);
 int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, int64_t M, int E,
                  float eps, hipStream_t s);
-int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, hipStream_t s);
+// log2q: q arrives pre-multiplied by log2(e) as well (the encoder folds it into the QKV epilogue's fp32 q scaling, so no
+// second 16-bit rounding of q); 0 = plain head_dim^-0.5 scaling, the public mst_attention* contract
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s);
 int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
-int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,
+int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q,
                      hipStream_t s);
-int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs,
+int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q,
                       hipStream_t s);
 int launch_patch_embed(const void* vol, int idt, int n, int H, int W, const void* wp, int dt,
                        const float* bias, const float* prefix, int n_prefix, const float* pos_patch,

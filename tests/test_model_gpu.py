@@ -38,7 +38,10 @@ CASES = {
 # The LieRE slice transformer (33 tokens re-partitioned into pseudo-heads) amplifies a given embedding error about
 # 2-4x more into the logits than the other fusions do (tools/fixture_errors.py: same 1.8e-3 embedding error in fp16,
 # 5.6e-3 on the logits vs <= 2.9e-3 elsewhere), so its logits tolerance is doubled in the 16-bit modes only.
-LOGIT_SCALE = {"liere": {"fp16": 2.0, "bf16": 2.0}}
+# 'linear' fusion feeds all D*E = 12,288 slice features straight into the head: the same per-feature error sums over 32x
+# more terms than a CLS read-out (measured 2.5e-2 .. 3.2e-2 in bf16 across kernel revisions at an unchanged 1.4e-2 embedding
+# error, against <= 1.6e-2 for the transformer fusions).
+LOGIT_SCALE = {"liere": {"fp16": 2.0, "bf16": 2.0}, "linear32": {"fp16": 2.0, "bf16": 2.0}}
 
 
 def build(name_kwargs, seed, mode, **extra):
