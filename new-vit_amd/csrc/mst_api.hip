@@ -4,6 +4,7 @@
 // stream, scratch comes from the caller's workspace, so a caller may capture a call into a hipGraph.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -210,8 +211,12 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         const int64_t Mc = (int64_t)c * N;
         const char* v = (const char*)vol + (size_t)s0 * H * W * in_sz;
         RUNK(MST_K_PATCH_EMBED, launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
-        // fused-LayerNorm pipeline (16-bit, E = 384): norm1 folded into QKV, norm2 + MLP in one kernel
-        bool fused = (dt != MST_F32) && E == 384;
+        // fused-LayerNorm pipeline (16-bit, E = 384): norm1 folded into QKV, norm2 + MLP in one kernel.  The fused MLP is a
+        // persistent kernel of 128-token tiles: below ~one tile per CU it leaves CUs idle (c1 shape, 4k tokens: 90 us per
+        // launch on 33 CUs against ~45 us for LN + fc1 + fc2 as three well-filled launches), so small calls take the unfused
+        // path.  The choice depends on the WHOLE call (n_slices x N), never on the chunking.
+        static const int64_t fused_min_tokens = getenv("MST_FUSED_MIN_TOKENS") ? atoll(getenv("MST_FUSED_MIN_TOKENS")) : 12288;   // measured crossover (tools/bench_crossover.py): 8k tokens unfused 1.57 vs 1.92 ms, 16k fused 2.34 vs 2.62
+        bool fused = (dt != MST_F32) && E == 384 && (int64_t)n_slices * N >= fused_min_tokens;
         for (int l = 0; l < w->depth && fused; ++l)
             fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
         if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
