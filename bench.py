@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--size", type=int, default=512, help="nominal in-plane size (padded up to a multiple of 14)")
     ap.add_argument("--chunk", type=int, default=0, help="slices per encoder pass (0 = auto)")
+    ap.add_argument("--parallelism", default="slice", choices=["slice", "dp"],
+                    help="N > 1: 'slice' = slices of every volume sharded over the ranks + one all-gather (north star, default); "
+                         "'dp' = whole volumes per rank, no exchange at all (SURVEY 8e: the better choice when B >= N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -104,13 +107,16 @@ def main():
                                   chunk_slices=args.chunk)
     model.load_state_dict(synth.synth_state_dict("s", 0))
     model = model.to(dev).eval()
-    if world > 1:
+    if world > 1 and args.parallelism == "slice":
         model.enable_slice_sharding()
 
     # synthetic N(0,1) volumes generated on the device (same on every rank), padded 512 -> 518, resident in HBM
     g = torch.Generator(device=dev)
     g.manual_seed(1)
-    vol = torch.randn((B, 1, D, args.size, args.size), generator=g, device=dev, dtype=torch.float32)
+    Bdev = Bl if (world > 1 and args.parallelism == "dp") else B      # dp: this rank's own volumes only
+    if world > 1 and args.parallelism == "dp":
+        g.manual_seed(1 + rank)
+    vol = torch.randn((Bdev, 1, D, args.size, args.size), generator=g, device=dev, dtype=torch.float32)
     if pad:
         lo = pad // 2
         vol = torch.nn.functional.pad(vol, (lo, pad - lo, lo, pad - lo))
@@ -218,7 +224,9 @@ def main():
             "config": {"workload": f"MST-DINOv2 (DinoV2ClassifierSlice, ViT-S/14) forward, {Bl} volumes/GPU of "
                                    f"{D}x{args.size}x{args.size} {args.dtype} zero-padded to {side}x{side} (N={N} tokens/slice)",
                        "global_batch_volumes": B, "slices": D, "in_plane": [side, side],
-                       "parallelism": "single GPU" if n_gpus == 1 else f"slice-sharded x{n_gpus} + all-gather of slice embeddings",
+                       "parallelism": "single GPU" if n_gpus == 1 else (
+                           f"slice-sharded x{n_gpus} + all-gather of slice embeddings" if args.parallelism == "slice"
+                           else f"data-parallel over volumes x{n_gpus}, no exchange"),
                        "weights": "synthetic (mst.synth seed 0), random init of the reference architecture"},
             "achieved_tflops": round(f_vol * value / 1e12, 1) if f_vol else None,
             "mfma_util": round(f_vol * value / (PEAK[args.dtype] * n_gpus), 4) if f_vol else None,
