@@ -9,6 +9,8 @@
 //
 // Reference arithmetic: F.linear at transformer_blocks.py:166,283,586; dino.py:135,166 (and the
 // encoder linears in fp32 mode).
+#include <stdlib.h>
+
 #include "mst_common.h"
 
 namespace {
@@ -142,6 +144,9 @@ int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, cons
     MST_CHECK_ARG(lda % 4 == 0 && ldw % 4 == 0, "gemm32: lda/ldw must be multiples of 4");
     MST_CHECK_ARG(M < (1ll << 31) - BM, "gemm32: M too large");
     if (M <= 0) return MST_OK;
+    static const bool small_ok = !(getenv("MST_GEMM32_SMALL") && atoi(getenv("MST_GEMM32_SMALL")) == 0);
+    if (small_ok && gemm32_small_applicable(M, N, K))   // across-slice stage: a few hundred rows (k_gemm32s.hip)
+        return launch_gemm32_small(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     switch (epi) {
         case MST_EPI_BIAS: return launch_t<MST_EPI_BIAS>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
         case MST_EPI_BIAS_GELU: return launch_t<MST_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);

@@ -157,6 +157,9 @@ int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+bool gemm32_small_applicable(int64_t M, int N, int K);
+int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                        int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols, hipStream_t s);
 int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, int64_t M, int E,
                  float eps, hipStream_t s);
 // log2q: q arrives pre-multiplied by log2(e) as well (the encoder folds it into the QKV epilogue's fp32 q scaling, so no

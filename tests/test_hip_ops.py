@@ -148,16 +148,19 @@ def test_gemm16_exact_integers_asymmetric(hip, dt):
     assert torch.equal(got.cpu(), a @ w.t())
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 2, 384), (4, 2, 96), (65, 1152, 384), (130, 96, 384), (260, 384, 384), (33, 48, 48), (1, 2, 12288)])
+@pytest.mark.parametrize("M,N,K", [(1, 2, 384), (4, 2, 96), (65, 1152, 384), (130, 96, 384), (260, 384, 384), (33, 48, 48), (1, 2, 12288),
+                                   (1024, 100, 64), (1025, 100, 64), (2080, 1152, 384)])
 def test_gemm32(hip, M, N, K):
+    """Exact-fp32 GEMM vs fp64: M <= 1024 runs the one-wave-per-tile kernel (k_gemm32s.hip), larger M the LDS-tiled one; both are
+    fp32 FMA chains in different k orders, so the bound is fp32 accumulation noise (2e-5 of the output scale at K = 12288)."""
     a, w, bias = rnd((M, K), 20), rnd((N, K), 21) / math.sqrt(K), rnd((N,), 22) * 0.1
     for epi in (0, 1, 2):
         got = hip.gemm(a.cuda(), w.cuda(), bias.cuda(), epilogue=epi)
-        assert scaled_err(got, _gemm_ref(a, w, bias, epi)) < 1e-5, epi
+        assert scaled_err(got, _gemm_ref(a, w, bias, epi)) < 2e-5, epi
     resid = rnd((M, N), 23)
     out = resid.cuda().clone()
     hip.gemm(a.cuda(), w.cuda(), bias.cuda(), epilogue=3, out=out)
-    assert scaled_err(out, _gemm_ref(a, w, bias, 3, None, resid)) < 1e-5
+    assert scaled_err(out, _gemm_ref(a, w, bias, 3, None, resid)) < 2e-5
 
 
 def test_gemm_rejects_bad_shapes(hip):
