@@ -314,12 +314,35 @@ __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qk
     for (int d = tid; d < hd; d += 256) q0[d] = to_f32(base[h * hd + d]);
     __syncthreads();
     float mx = -INFINITY;
-    for (int j = tid; j < N; j += 256) {
-        const T* kp = base + (int64_t)j * ld + E + h * hd;
-        float a = 0.f;
-        for (int d = 0; d < hd; ++d) a = fmaf(q0[d], to_f32(kp[d]), a);
-        sc[j] = a;
-        mx = fmaxf(mx, a);
+    if (hd == 64) {
+        // eight lanes per key row: each loads 8 consecutive dims (16 B for the 16-bit types: whole 128-byte K rows per 8 lanes)
+        // and the partial dot products meet in three shuffles; 32 keys per pass of the workgroup
+        const int sub = tid & 7;
+        float qr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qr[i] = q0[sub * 8 + i];
+        for (int j0 = 0; j0 < N; j0 += 32) {
+            const int j = j0 + (tid >> 3);
+            const T* kp = base + (int64_t)(j < N ? j : N - 1) * ld + E + h * 64 + sub * 8;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a = fmaf(qr[i], to_f32(kp[i]), a);
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (j < N) {
+                if (sub == 0) sc[j] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    } else {
+        for (int j = tid; j < N; j += 256) {
+            const T* kp = base + (int64_t)j * ld + E + h * hd;
+            float a = 0.f;
+            for (int d = 0; d < hd; ++d) a = fmaf(q0[d], to_f32(kp[d]), a);
+            sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
     }
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
