@@ -397,6 +397,138 @@ __global__ __launch_bounds__(256) void probs_full_kernel(const T* __restrict__ q
     for (int j = lane; j < N; j += 64) po[j] = sc[j] * inv;
 }
 
+// ---- full probabilities on the matrix pipe (16-bit inputs, head_dim 64): two passes over the K tiles of a (sequence, head) per
+// 128-query workgroup.  Pass 1 is the flash loop without V: S^T = K . Q^T puts a query on a lane, so the running max / sum are
+// in-lane.  Pass 2 recomputes the tile as S = Q . K^T (the same two register fragments, operands swapped): now a lane holds ONE
+// key of 16 query rows, i.e. 32 lanes write 128 contiguous bytes of a probability row.  The kernel is bound by its 4 N^2-byte
+// output (2.9 GB per layer at 64 x 518^2): the one-wave-per-row VALU version took ~140 ms per layer.
+template <typename T>
+__global__ __launch_bounds__(256) void probs_full16_kernel(const T* __restrict__ qkv, float* __restrict__ probs, int N,
+                                                           int heads, int log2q) {
+    typedef typename V8<T>::type vec8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 128 * 8];
+    char* const Ks = smem;
+    float* const stat = reinterpret_cast<float*>(smem + 2 * K_TILE_BYTES);   // [128 q][2]: max * log2e, 1 / sum
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = (N + 127) >> 7;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = tile % nqb, h = (tile / nqb) % heads, seq = tile / (nqb * heads);
+    const int E = heads * 64, ld = 3 * E;
+    const T* base = qkv + (int64_t)seq * N * ld;
+    const int h2 = lane >> 5;
+    const int q = qb * 128 + wave * 32 + (lane & 31);
+    const float sc = log2q ? 1.0f : LOG2E;               // scores -> log2 domain
+    vec8 bq[4];
+    {
+        const int qc = q < N ? q : N - 1;
+        const T* qp = base + (int64_t)qc * ld + h * 64 + h2 * 8;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) bq[ds] = *reinterpret_cast<const vec8*>(qp + ds * 16);
+    }
+    const int sr = tid >> 2, sc0 = (tid & 3) * 2;        // K staging: thread -> key row sr, chunks sc0, sc0 + 1
+    u32x4 rk0, rk1;
+    auto gload = [&](int t) {
+        int key = t * 64 + sr;
+        key = key < N ? key : N - 1;
+        const T* kp = base + (int64_t)key * ld + E + h * 64 + sc0 * 8;
+        rk0 = *reinterpret_cast<const u32x4*>(kp);
+        rk1 = *reinterpret_cast<const u32x4*>(kp + 8);
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<u32x4*>(Ks + buf * K_TILE_BYTES + sr * K_ROW + sc0 * 16) = rk0;
+        *reinterpret_cast<u32x4*>(Ks + buf * K_TILE_BYTES + sr * K_ROW + sc0 * 16 + 16) = rk1;
+    };
+    const int k_lane_off = (lane & 31) * K_ROW + h2 * 16;
+    const int nt = (N + 63) >> 6;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- pass 1: row statistics
+    float m_run = -INFINITY, l_run = 0.f;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* Kb = Ks + buf * K_TILE_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = zero16;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
+                s[kb] = mfma32(a, bq[ds], s[kb]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                s[kb][r] = key < N ? s[kb][r] * sc : -INFINITY;
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        float lsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum += __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + lsum;
+        m_run = m_new;
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (h2 == 0) {
+            stat[(wave * 32 + (lane & 31)) * 2] = m_run;
+            stat[(wave * 32 + (lane & 31)) * 2 + 1] = 1.0f / l_tot;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: S = Q . K^T, lane = key, registers = the wave's 16 query rows (r&3) + 8 (r>>2) + 4 h2 of this half
+    float mrow[16], irow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ql = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        mrow[r] = stat[ql * 2];
+        irow[r] = stat[ql * 2 + 1];
+    }
+    float* const pbase = probs + (((int64_t)seq * heads + h) * N) * N;
+    gload(0);
+    __syncthreads();                                     // every wave is done with pass 1's last tile and with `stat`
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        const char* Kb = Ks + buf * K_TILE_BYTES;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s = zero16;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
+                s = mfma32(bq[ds], a, s);                // operands swapped: D[q][key]
+            }
+            const int key = t * 64 + kb * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qb * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                if (key < N && qq < N) pbase[(int64_t)qq * N + key] = __builtin_amdgcn_exp2f(s[r] * sc - mrow[r]) * irow[r];
+            }
+        }
+        if (t + 1 < nt) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s) {
@@ -422,6 +554,14 @@ int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int h
 }
 
 int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q, hipStream_t s) {
+    if (hd == 64 && (dt == MST_BF16 || dt == MST_F16)) {   // matrix-pipe path
+        MST_CHECK_ARG(N > 0 && n_seq > 0 && heads > 0, "probs_full: bad sizes");
+        const int64_t nwg = (int64_t)((N + 127) / 128) * heads * n_seq;
+        MST_CHECK_ARG(nwg < (1ll << 31), "probs_full: grid too large");
+        if (dt == MST_BF16) probs_full16_kernel<bf16_t><<<dim3((unsigned)nwg), dim3(256), 0, s>>>((const bf16_t*)qkv, probs, N, heads, log2q);
+        else probs_full16_kernel<f16_t><<<dim3((unsigned)nwg), dim3(256), 0, s>>>((const f16_t*)qkv, probs, N, heads, log2q);
+        return mst_check_launch("probs_full16");
+    }
     MST_CHECK_ARG(N > 0 && N <= 3800 && hd > 0 && hd <= 256, "probs_full: N=%d hd=%d unsupported", N, hd);
     const dim3 grid((N + 3) / 4, heads, n_seq), block(256);
     const size_t sh = (size_t)4 * (hd + N) * sizeof(float);
