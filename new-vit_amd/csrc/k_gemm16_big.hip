@@ -250,7 +250,8 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
-    int nblk = ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256;
+    const int cus = mst_persistent_grid();
+    int nblk = ntiles < cus ? ((ntiles + 7) / 8) * 8 : cus;
     kern<<<dim3(nblk), dim3(512), LDS_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K,
                                                    gamma, cs, sc, tiles_n, ntiles);
     return mst_check_launch("gemm16_big");

@@ -29,7 +29,7 @@ constexpr int LDS_BYTES = STG_OFF + 4 * 16 * (96 * 4 + 16);   // ring + staging 
 constexpr int NI = 6, NJ = 8;                     // 16-wide sub-tiles per wave: N, M
 constexpr int PA = 2, PW = 6, PS = PA + PW;       // LDS-DMA pieces per wave per stage: A, W, total
 #ifndef MID_NBLK
-#define MID_NBLK 256
+#define MID_NBLK 0        // 0 = one workgroup per compute unit of the device
 #endif
 constexpr int NBLK = MID_NBLK;
 
@@ -221,7 +221,8 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int ntiles = tiles_m * tiles_n;
-    int nblk = ntiles < NBLK ? ((ntiles + 7) / 8) * 8 : NBLK;
+    const int cus = NBLK > 0 ? NBLK : mst_persistent_grid();
+    int nblk = ntiles < cus ? ((ntiles + 7) / 8) * 8 : cus;
     kern<<<dim3(nblk), dim3(256), LDS_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma,
                                                    cs, sc, tiles_n, ntiles);
     return mst_check_launch("gemm16_mid");

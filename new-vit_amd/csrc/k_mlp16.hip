@@ -395,7 +395,8 @@ int launch_t(float* x, void* xn_out, const void* wpack, const float* b1f, const 
     auto kern = mlp16_kernel<T>;
     mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int ntiles = (int)((M + 127) / 128);
-    const int nblk = ntiles < 256 ? ntiles : 256;
+    const int cus = mst_persistent_grid();
+    const int nblk = ntiles < cus ? ntiles : cus;
     kern<<<dim3(nblk), dim3(512), LDS_BYTES, s>>>(x, (T*)xn_out, (const char*)wpack, b1f, b2, nullptr, (int)M, ntiles, eps);
     return mst_check_launch("mlp16");
 }

@@ -40,6 +40,20 @@ void mst_allow_lds(const void* kernel, int bytes, mst_lds_once* slot) {
     slot->done_mask |= 1ull << dev;
 }
 
+int mst_persistent_grid(void) {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus[dev] = n / 8 * 8;
+    }
+    return cus[dev];
+}
+
 // ---- optional per-kernel event timing (bench only) -------------------------------------------------
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; };

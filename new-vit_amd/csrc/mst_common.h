@@ -139,6 +139,9 @@ int mst_check_launch(const char* what);
 // several GPUs.  Thread-safe; `slot` is a static per-kernel token owned by the call site.
 struct mst_lds_once { unsigned long long done_mask = 0; };
 void mst_allow_lds(const void* kernel, int bytes, mst_lds_once* slot);
+// Compute units of the current device (256 on an MI355X in SPX mode, 32 per logical GPU in CPX mode), cached per device and
+// rounded down to a multiple of 8 (the persistent kernels deal tile ids to the 8 XCDs): the size of a persistent grid.
+int mst_persistent_grid(void);
 
 // kernel launchers shared between translation units (all asynchronous on `s`)
 int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
