@@ -1,3 +1,11 @@
-"""Same import surface as the reference's mst/models/__init__.py:1-2."""
+"""Import surface of the reference's ``mst.models`` package (mst/models/__init__.py:1-2; scripts/main_train.py:18-19 and
+scripts/main_predict.py:27-28 import from here and from the sub-modules).
+
+``DinoV2ClassifierSlice`` is the MI355X hot path; ``DinoV3ClassifierSlice``, ``ResNet`` and ``ResNetSliceTrans`` exist so that
+the scripts' imports and ``isinstance`` dispatch keep working (they raise on construction: out of scope).
+"""
+from .base_model import BasicClassifier, BasicModel
+from .dino import DinoV2ClassifierSlice, DinoV3ClassifierSlice
 from .resnet import ResNet, ResNetSliceTrans
-from .dino import DinoV2ClassifierSlice
+
+__all__ = ["BasicModel", "BasicClassifier", "DinoV2ClassifierSlice", "DinoV3ClassifierSlice", "ResNet", "ResNetSliceTrans"]
