@@ -35,7 +35,8 @@ for p in (ROOT, ROOT / "new-vit_amd"):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}   # dense MFMA, MI355X_MICROARCH.md
+# dense MFMA, MI355X_MICROARCH.md; the fp8 mode issues the NON-scaled v_mfma_f32_16x16x32_fp8_fp8, which runs at the bf16 rate
+PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12, "fp8": 2.5e15}
 E, HEADS, DEPTH = 384, 6, 12
 
 
@@ -58,7 +59,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp8"],
+                    help="bf16 is the BASELINE metric's dtype; fp8 = e4m3 linear layers on a bf16 carrier (configs[4])")
     ap.add_argument("--volumes", type=int, default=4, help="volumes per GPU")
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--size", type=int, default=512, help="nominal in-plane size (padded up to a multiple of 14)")
@@ -101,7 +103,7 @@ def main():
     B = Bl * n_gpus                              # global batch (weak scaling)
     if D % n_gpus:
         raise SystemExit(f"--slices {D} must be divisible by the number of GPUs {n_gpus}")
-    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp8": torch.bfloat16}[args.dtype]
 
     model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=args.dtype,
                                   chunk_slices=args.chunk)

@@ -71,6 +71,21 @@ int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ld
              void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
              const float* gamma, float col_scale, int scale_cols, mst_stream_t stream);
 
+/* FP8 linear layers (BASELINE.json configs[4]): OCP e4m3 operands, one scale per tensor from its
+ * absolute maximum, fp32 accumulate.  The reference has no fp8 code; this is F.linear (attention.py:58,67; mlp.py:35,38)
+ * with both operands rounded to e4m3:  y = (sa*sw) * (q(x/sa) . q(W/sw)^T) + b,  sa = max|x|/448,  sw = max|W|/448.
+ *
+ * mst_quantize_fp8: x (bf16/fp16, n elements, n % 8 == 0) -> out8[n] e4m3 bytes = rne(x * 448/amax), where *amax (device
+ *   fp32) = max(*amax on entry, max|x|): pass 0 for a fresh per-tensor scale, or a calibrated floor.  Stream-ordered, no
+ *   host synchronisation.
+ * mst_gemm_fp8: C[M,N] = epi((*a_amax/448 * w_scale) * A8[M,K] . W8[N,K]^T + bias); A8, W8 e4m3 bytes with K-contiguous
+ *   rows; K % 128 == 0, N % 128 == 0, lda/ldw % 16 == 0; c_dtype f32 / bf16 / fp16; epilogues, gamma, col_scale and
+ *   scale_cols as mst_gemm. */
+int mst_quantize_fp8(const void* x, int dtype, int64_t n, float* amax, void* out8, mst_stream_t stream);
+int mst_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
+                 float w_scale, void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                 const float* gamma, float col_scale, int scale_cols, mst_stream_t stream);
+
 /* softmax(q k^T) v per (sequence, head), q pre-scaled: attention.py:56-66 (== xformers
  * memory_efficient_attention, attention.py:84).  qkv [n_seq*N, 3*heads*head_dim] packed as the
  * reference's fused projection lays it out (q | k | v, head-major inside each); out
@@ -136,6 +151,10 @@ typedef struct mst_vit_layer {
      *   mlp_pack / fc1_bf / fc2_bf: see mst_mlp_fused                        (norm2 and ls2 folded) */
     const void* qkv_wf; const float* qkv_bf;
     const void* mlp_pack; const float* fc1_bf; const float* fc2_bf;
+    /* Optional FP8 form (mst_vit_weights.fp8_linear): the four block weights as e4m3 bytes, same [out,in] layout, with their
+     * per-tensor scales w8_scale[] = max|W|/448 in the order qkv, proj, fc1, fc2 (see mst_gemm_fp8) */
+    const void* qkv_w8; const void* proj_w8; const void* fc1_w8; const void* fc2_w8;
+    float w8_scale[4];
 } mst_vit_layer;
 
 typedef struct mst_vit_weights {
@@ -148,6 +167,9 @@ typedef struct mst_vit_weights {
     const float* pos_patch;       /* [grid_h*grid_w, E] */
     const mst_vit_layer* layers;  /* [depth], host memory */
     const float* norm_w; const float* norm_b; /* vision_transformer.py:165 */
+    int fp8_linear;               /* 1: the blocks' four linear layers run as mst_gemm_fp8 with dynamic per-tensor activation
+                                   * scales (one per GEMM call, i.e. per chunk of slices); needs a 16-bit compute_dtype, which
+                                   * stays the type of LayerNorm outputs, q/k/v and the attention kernel */
 } mst_vit_weights;
 
 /* DinoVisionTransformer.forward on n_slices gray slices (vision_transformer.py:254-270,324-329;

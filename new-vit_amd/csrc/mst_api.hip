@@ -111,6 +111,18 @@ int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ld
                          scale_cols, (hipStream_t)stream);
 }
 
+int mst_quantize_fp8(const void* x, int dtype, int64_t n, float* amax, void* out8, mst_stream_t stream) {
+    MST_CHECK_ARG(x && amax && out8, "quantize_fp8: null pointer");
+    return launch_quant8(x, dtype, n, amax, out8, (hipStream_t)stream);
+}
+
+int mst_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
+                 float w_scale, void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                 const float* gamma, float col_scale, int scale_cols, mst_stream_t stream) {
+    return launch_gemm8(A8, lda, W8, ldw, bias, a_amax, w_scale, C, c_dtype, ldc, M, N, K, epilogue, gamma, col_scale,
+                        scale_cols, (hipStream_t)stream);
+}
+
 int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, void* out,
                   mst_stream_t stream) {
     MST_CHECK_ARG(qkv && out, "attention: null pointer");
@@ -155,7 +167,9 @@ int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const fl
 //   x   fp32 [Mc, E]      residual stream
 //   xn  T    [Mc, E]      LayerNorm output; reused as the attention output
 //   big T    [Mc, 4E]     qkv [Mc, 3E] during attention, then the MLP hidden [Mc, 4E]
-static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn, size_t* off_big, size_t* total) {
+//   fp8_linear only:  a8 u8 [Mc, 4E] (the quantised input of the current GEMM) | amax f32 [depth][4]
+static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn, size_t* off_big, size_t* total,
+                      size_t* off_a8 = nullptr, size_t* off_amax = nullptr) {
     const size_t Mc = (size_t)chunk * N, E = (size_t)w->embed_dim, ts = dt_size(w->compute_dtype);
     size_t o = 0;
     o += align_up(Mc * E * 4, 256);
@@ -163,6 +177,12 @@ static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn
     o += align_up(Mc * E * ts, 256);
     *off_big = o;
     o += align_up(Mc * 4 * E * ts, 256);
+    if (w->fp8_linear) {
+        if (off_a8) *off_a8 = o;
+        o += align_up(Mc * 4 * E, 256);
+        if (off_amax) *off_amax = o;
+        o += align_up((size_t)w->depth * 4 * sizeof(float), 256);
+    }
     *total = o;
 }
 
@@ -190,8 +210,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     MST_CHECK_ARG(n_layers_probs >= 0 && n_layers_probs <= w->depth, "vit_encode: n_layers_probs=%d", n_layers_probs);
     const int R = w->num_registers, Np = w->grid_h * w->grid_w, N = 1 + R + Np;
     if (chunk_slices > n_slices) chunk_slices = n_slices;
-    size_t off_xn, off_big, total;
-    vit_carve(w, N, chunk_slices, &off_xn, &off_big, &total);
+    size_t off_xn, off_big, total, off_a8 = 0, off_amax = 0;
+    vit_carve(w, N, chunk_slices, &off_xn, &off_big, &total, &off_a8, &off_amax);
     if (ws_bytes < total) {
         mst_set_error("vit_encode: workspace %zu < %zu bytes", ws_bytes, total);
         return MST_EWORKSPACE;
@@ -199,6 +219,16 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     float* x = (float*)ws;
     void* xn = (char*)ws + off_xn;
     void* big = (char*)ws + off_big;
+    const bool fp8 = w->fp8_linear != 0;
+    void* a8 = fp8 ? (char*)ws + off_a8 : nullptr;
+    float* amax = fp8 ? (float*)((char*)ws + off_amax) : nullptr;
+    if (fp8) {
+        MST_CHECK_ARG(dt == MST_F16 || dt == MST_BF16, "vit_encode: fp8_linear needs a 16-bit compute dtype");
+        MST_CHECK_ARG(E % 128 == 0, "vit_encode: fp8_linear needs embed_dim %% 128 == 0 (got %d)", E);
+        for (int l = 0; l < w->depth; ++l)
+            MST_CHECK_ARG(w->layers[l].qkv_w8 && w->layers[l].proj_w8 && w->layers[l].fc1_w8 && w->layers[l].fc2_w8,
+                          "vit_encode: fp8_linear set but layer %d has no e4m3 weights", l);
+    }
     const size_t in_sz = dt_size(in_dtype);
     // head_dim^-0.5, head_dim = 64 (attention.py:48); the 16-bit attention kernels work in the log2 domain, so log2(e) rides
     // on the same fp32 multiply of the QKV epilogue (one rounding of q, not two)
@@ -230,14 +260,24 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         // launch on 33 CUs against ~45 us for LN + fc1 + fc2 as three well-filled launches), so small calls take the unfused
         // path.  The choice depends on the WHOLE call (n_slices x N), never on the chunking.
         static const int64_t fused_min_tokens = getenv("MST_FUSED_MIN_TOKENS") ? atoll(getenv("MST_FUSED_MIN_TOKENS")) : 12288;   // measured crossover (tools/bench_crossover.py): 8k tokens unfused 1.57 vs 1.92 ms, 16k fused 2.34 vs 2.62
-        bool fused = (dt != MST_F32) && E == 384 && (int64_t)n_slices * N >= fused_min_tokens;
+        bool fused = !fp8 && (dt != MST_F32) && E == 384 && (int64_t)n_slices * N >= fused_min_tokens;
         for (int l = 0; l < w->depth && fused; ++l)
             fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
         if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
+        if (fp8 && hipMemsetAsync(amax, 0, (size_t)w->depth * 4 * sizeof(float), s) != hipSuccess) {
+            mst_set_error("vit_encode: hipMemsetAsync(amax) failed");
+            return MST_ELAUNCH;
+        }
         for (int l = 0; l < w->depth; ++l) {
             const mst_vit_layer* L = &w->layers[l];
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
-            if (fused) {
+            if (fp8) {
+                // every linear layer: quantise its input with a fresh per-tensor scale (this chunk's max|x|), e4m3 GEMM
+                float* am = amax + l * 4;
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, s));
+                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+            } else if (fused) {
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             } else {
                 RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
@@ -250,6 +290,17 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, log2q, s));
             if (dt == MST_F32) RUNK(MST_K_ATTENTION, launch_attn32((const float*)big, c, N, heads, (float*)xn, s));
             else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
+            if (fp8) {
+                float* am = amax + l * 4;
+                RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, s));
+                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, s));
+                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
+                RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, s));
+                RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+                continue;
+            }
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
             // x += ls2(fc2(gelu(fc1(norm2 x))))                        block.py:93-94,113
             if (fused) {

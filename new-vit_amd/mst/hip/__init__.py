@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Sequence, Optional
+from typing import Sequence, Optional, Tuple
 
 import torch
 
@@ -23,7 +23,10 @@ FUSION_TRANSFORMER, FUSION_LINEAR, FUSION_AVERAGE = 0, 1, 2
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 TORCH_DT = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
 DT_NAMES = {"fp32": F32, "f32": F32, "float32": F32, "fp16": F16, "f16": F16, "float16": F16,
-            "bf16": BF16, "bfloat16": BF16}
+            "bf16": BF16, "bfloat16": BF16,
+            # e4m3 linear layers on a bf16 carrier (LayerNorm outputs, q/k/v, attention): mst_vit_weights.fp8_linear
+            "fp8": BF16, "f8": BF16, "fp8_e4m3": BF16}
+FP8_NAMES = ("fp8", "f8", "fp8_e4m3")
 
 _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
@@ -31,14 +34,15 @@ _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
-                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf")]
+                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf",
+                                   "qkv_w8", "proj_w8", "fc1_w8", "fc2_w8")] + [("w8_scale", C.c_float * 4)]
 
 
 class VitWeights(C.Structure):
     _fields_ = [("embed_dim", _i), ("depth", _i), ("num_heads", _i), ("num_registers", _i),
                 ("compute_dtype", _i), ("grid_h", _i), ("grid_w", _i),
                 ("patch_w", _vp), ("patch_b", _vp), ("prefix", _vp), ("pos_patch", _vp),
-                ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp)]
+                ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp), ("fp8_linear", _i)]
 
 
 class FusionWeights(C.Structure):
@@ -55,6 +59,8 @@ SIGNATURES = {
     "mst_last_error": (C.c_char_p, []),
     "mst_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _vp]),
     "mst_gemm": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp]),
+    "mst_quantize_fp8": (_i, [_vp, _i, _i64, _vp, _vp, _vp]),
+    "mst_gemm_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp]),
     "mst_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -148,6 +154,43 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
         out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
     _check(load().mst_gemm(ptr(a), dt_of(a), K, ptr(w), K, ptr(bias), ptr(out), dt_of(out), N, M, N, K, epilogue,
                            ptr(gamma), col_scale, scale_cols, stream_of(a)), "mst_gemm")
+    return out
+
+
+F8_MAX = 448.0      # largest finite OCP e4m3
+
+
+def quantize_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, float]:
+    """Per-tensor e4m3 form of a weight matrix: (bytes [out,in] uint8, scale = max|W|/448), W ~ scale * e4m3(bytes).  Done
+    once per weight version with torch's round-to-nearest-even cast (host-side preparation, like the other packers)."""
+    w = w.detach().to(torch.float32)
+    amax = float(w.abs().max())
+    scale = amax / F8_MAX if amax > 0 else 1.0
+    q = (w / scale).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale
+
+
+def quantize_fp8(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mst_quantize_fp8: (e4m3 bytes with x's shape, amax fp32 [1] on the device)."""
+    _dev(x, "quantize_fp8")
+    if amax is None:
+        amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _check(load().mst_quantize_fp8(ptr(x), dt_of(x), x.numel(), ptr(amax), ptr(out), stream_of(x)), "mst_quantize_fp8")
+    return out, amax
+
+
+def gemm_fp8(a8: torch.Tensor, a_amax: torch.Tensor, w8: torch.Tensor, w_scale: float, bias: Optional[torch.Tensor], *,
+             epilogue: int = EPI_BIAS, out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
+             gamma: Optional[torch.Tensor] = None, col_scale: float = 1.0, scale_cols: int = 0) -> torch.Tensor:
+    _dev(a8, "gemm_fp8")
+    _dev(w8, "gemm_fp8")
+    M, K = a8.shape
+    N = w8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    _check(load().mst_gemm_fp8(ptr(a8), K, ptr(w8), K, ptr(bias), ptr(a_amax), w_scale, ptr(out), dt_of(out), N, M, N, K,
+                               epilogue, ptr(gamma), col_scale, scale_cols, stream_of(a8)), "mst_gemm_fp8")
     return out
 
 

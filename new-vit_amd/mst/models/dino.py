@@ -7,9 +7,11 @@ parameter containers only: all arithmetic of the forward runs in the hand-writte
 libmst_hip.so through ``mst.hip`` (C ABI: include/mst_hip.h).  There is no PyTorch/CPU fallback.
 
 Build-specific (keyword-only, all optional) controls -- none changes the maths of the reference:
-  compute_dtype   'bf16' (default) | 'fp16' | 'fp32'  MFMA operand type of the encoder GEMMs and
+  compute_dtype   'bf16' (default) | 'fp16' | 'fp32' | 'fp8'  MFMA operand type of the encoder GEMMs and
                   attention (fp32 accumulate / residual / LayerNorm / softmax always). fp16 is the
                   TF32-class path (reference GPUs run TF32: main_predict.py:195), fp32 is exact.
+                  'fp8' (BASELINE configs[4]): the blocks' four linear layers with OCP e4m3 operands and
+                  per-tensor absmax scales (dynamic for activations), everything else as in bf16 mode.
   chunk_slices    slices encoded per pass (activations of a pass sized for the Infinity Cache).
   full_attention_maps  keep the complete [n,h,N,N] softmax of every block on ``save_attn`` (needed
                   only by ``get_attention_cls``); default keeps the CLS rows ([n,h,1,N]) only.
@@ -290,6 +292,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
                                "There is no CPU fallback.")
         cdt = hip.DT_NAMES[self.compute_dtype_name]
         tdt = hip.TORCH_DT[cdt]
+        fp8 = self.compute_dtype_name in hip.FP8_NAMES
         keep: List[torch.Tensor] = []
 
         def f32(t):
@@ -325,6 +328,15 @@ class DinoV2ClassifierSlice(BasicClassifier):
             L.fc1_w, L.fc1_b = hip.ptr(cmp(b.mlp.fc1.weight)), hip.ptr(f32(b.mlp.fc1.bias))
             L.fc2_w, L.fc2_b = hip.ptr(cmp(b.mlp.fc2.weight)), hip.ptr(f32(b.mlp.fc2.bias))
             L.ls2 = hip.ptr(f32(b.ls2.gamma)) if hasattr(b, "ls2") else None
+            if fp8:
+                # BASELINE configs[4]: the four block matrices as OCP e4m3 bytes + per-tensor scales (mst_gemm_fp8)
+                for j, (name, lin) in enumerate((("qkv_w8", b.attn.qkv), ("proj_w8", b.attn.proj),
+                                                 ("fc1_w8", b.mlp.fc1), ("fc2_w8", b.mlp.fc2))):
+                    q8, sc = hip.quantize_weight_fp8(lin.weight.to(dev))
+                    keep.append(q8)
+                    setattr(L, name, hip.ptr(q8))
+                    L.w8_scale[j] = sc
+                continue
             if cdt != hip.F32 and E == 384:
                 # fused-LayerNorm form: norm1 folded into QKV, norm2 folded into the packed MLP (mst_mlp_fused)
                 with torch.no_grad():
@@ -342,6 +354,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         vit = hip.VitWeights()
         vit.embed_dim, vit.depth, vit.num_heads, vit.num_registers = E, enc.depth, enc.num_heads, R
         vit.compute_dtype = cdt
+        vit.fp8_linear = 1 if fp8 else 0
         vit.patch_w, vit.patch_b = hip.ptr(wp), hip.ptr(f32(enc.patch_embed.proj.bias))
         vit.prefix = hip.ptr(prefix)
         vit.layers = layers

@@ -106,41 +106,71 @@ def prepare_tokens(sd: SD, slices: Tensor) -> Tensor:
     return x
 
 
-def vit_attention(x: Tensor, sd: SD, p: str, heads: int) -> Tuple[Tensor, Tensor]:
+F8_MAX = 448.0   # largest finite OCP e4m3
+
+
+def fp8_e4m3(x: Tensor) -> Tuple[Tensor, float]:
+    """Per-tensor e4m3 quantisation: (values representable in e4m3 as fp32, scale = max|x|/448), x ~ scale * values.
+    The multiplier 448/max|x| is formed and applied in fp32, rounding to e4m3 is to nearest-even."""
+    amax = x.detach().abs().max().to(torch.float32)
+    if float(amax) == 0.0:
+        return torch.zeros_like(x, dtype=torch.float32), 1.0
+    inv = torch.tensor(F8_MAX, dtype=torch.float32) / amax
+    q = (x.to(torch.float32) * inv).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, float(amax) / F8_MAX
+
+
+def fp8_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """F.linear with OCP-e4m3 operands, per-tensor absmax scales and wide accumulation -- the arithmetic BASELINE.json
+    configs[4] / SURVEY.md 8d row c5 name ("fp8-e4m3 operands, per-tensor scales from absmax").  PARITY UNPINNED: the
+    reference has no fp8 code; this restates F.linear (attention.py:58,67; mlp.py:35,38) with both operands rounded."""
+    xq, sx = fp8_e4m3(x)
+    wq, sw = fp8_e4m3(w)
+    y = (xq.double() @ wq.double().t()) * (sx * sw)
+    return (y + (b.double() if b is not None else 0.0)).to(x.dtype)
+
+
+_LINEAR = {"exact": F.linear, "fp8": fp8_linear}
+
+
+def vit_attention(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact") -> Tuple[Tensor, Tensor]:
     """attention.py:56-69 (== dino.py:226-243 with the softmax kept).  Returns (out, probs)."""
     n, N, C = x.shape
     d = C // heads
-    qkv = F.linear(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+    lin = _LINEAR[linear]
+    qkv = lin(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
     qkv = qkv.reshape(n, N, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
     probs = (q @ k.transpose(-2, -1)).softmax(dim=-1)
     out = (probs @ v).transpose(1, 2).reshape(n, N, C)
-    return F.linear(out, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), probs
+    return lin(out, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), probs
 
 
-def vit_block(x: Tensor, sd: SD, p: str, heads: int) -> Tuple[Tensor, Tensor]:
+def vit_block(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact") -> Tuple[Tensor, Tensor]:
     """block.py:89-114 eval branch: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)); LN eps 1e-6."""
-    a, probs = vit_attention(layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6), sd, p, heads)
+    lin = _LINEAR[linear]
+    a, probs = vit_attention(layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6), sd, p, heads, linear)
     if (p + ".ls1.gamma") in sd:  # layer_scale.py:26-27
         a = a * sd[p + ".ls1.gamma"]
     x = x + a
     h = layer_norm(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
-    h = F.linear(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])      # mlp.py:34-40
-    h = F.linear(gelu_erf(h), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    h = lin(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])           # mlp.py:34-40
+    h = lin(gelu_erf(h), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
     if (p + ".ls2.gamma") in sd:
         h = h * sd[p + ".ls2.gamma"]
     return x + h, probs
 
 
-def vit_encode(sd: SD, slices: Tensor, model_size: str = "s", keep: str = "none"):
+def vit_encode(sd: SD, slices: Tensor, model_size: str = "s", keep: str = "none", linear: str = "exact"):
     """DinoVisionTransformer.forward (vision_transformer.py:254-270,324-329) -> normalised CLS [n,E].
 
-    keep: 'none' | 'cls' (CLS row of every block's softmax, [n,h,1,N] each) | 'full' ([n,h,N,N])."""
+    keep: 'none' | 'cls' (CLS row of every block's softmax, [n,h,1,N] each) | 'full' ([n,h,N,N]).
+    linear: 'exact' (the reference) | 'fp8' (the blocks' four linear layers through fp8_linear; everything else unchanged)."""
     cfg = VIT_CFG[model_size]
     x = prepare_tokens(sd, slices)
     maps: List[Tensor] = []
     for i in range(cfg["depth"]):
-        x, probs = vit_block(x, sd, _block_prefix(sd, i), cfg["num_heads"])
+        x, probs = vit_block(x, sd, _block_prefix(sd, i), cfg["num_heads"], linear)
         if keep == "cls":
             maps.append(probs[:, :, :1].clone())
         elif keep == "full":
@@ -234,13 +264,13 @@ def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
 # --------------------------------------------------------------------------------------------
 def forward(sd: SD, source: Tensor, *, model_size: str = "s", slice_fusion_type: str = "transformer",
             src_key_padding_mask: Optional[Tensor] = None, rotary: Optional[str] = None,
-            without_linear: bool = False, keep: str = "none") -> Dict[str, Tensor]:
+            without_linear: bool = False, keep: str = "none", linear: str = "exact") -> Dict[str, Tensor]:
     """DinoV2ClassifierSlice.forward (dino.py:110-167).  source = [B,C,D,H,W]; channels become extra slices, channel
     fastest ('b c d h w -> (b d c) h w', l.125).
 
     Returns dict(logits|features, emb [B*D,E], vit_maps list, slice_map [B,12,L,L] or None)."""
     B, C, D, H, W = source.shape
-    emb, maps = vit_encode(sd, source.permute(0, 2, 1, 3, 4).reshape(B * D * C, H, W), model_size, keep)   # l.125-131
+    emb, maps = vit_encode(sd, source.permute(0, 2, 1, 3, 4).reshape(B * D * C, H, W), model_size, keep, linear)   # l.125-131
     x = emb
     if "bottleneck.weight" in sd:                                                    # l.134-135
         x = F.linear(x, sd["bottleneck.weight"], sd["bottleneck.bias"])

@@ -1,0 +1,202 @@
+"""FP8 (OCP e4m3) linear layers: BASELINE.json configs[4] / SURVEY.md 8d row c5.
+
+The reference has no fp8 code, so the arithmetic is the one BASELINE names -- e4m3 operands, one absmax scale per tensor, wide
+accumulation -- restated in oracle/mst_oracle.py::fp8_linear (parity unpinned by construction).  Checked here:
+  * mst_quantize_fp8 is BIT-EXACT against torch's round-to-nearest-even float8_e4m3fn cast (byte work);
+  * mst_gemm_fp8 equals the fp64 product of the dequantised operands, every epilogue, ragged M, and is EXACT on integer
+    operands (catches any k-order / row-column slip).  Tolerance 1e-4 of max|C|: v_mfma_f32_16x16x32_fp8_fp8 aligns the 32
+    products of one instruction to a common exponent before adding them, which costs a few low bits -- measured 3.0e-5 at
+    K = 384 (the 16-bit MFMA path measures 4e-6 on the same shapes);
+  * compute_dtype='fp8' against the oracle with linear='fp8':
+      - ONE block on identical inputs (depth-1 encoder): the only differences are values that the product path's bf16 carriers
+        (LayerNorm output, q/k/v, attention output, GELU output) move across an e4m3 rounding boundary.  A bf16 rounding
+        (2^-9) flips about 1.5 % of the e4m3 roundings (grid 2^-4), each by a whole grid step: ~0.4 of the quantisation noise
+        per quantised tensor.  Measured 4.1e-2 against a block quantisation noise of 8.1e-2; asserted < 0.75 of the noise
+        (a wrong scale, a dropped bias or a k-slip gives a multiple of it);
+      - the whole 12-block forward.  Rounding to 3 mantissa bits makes the forward chaotic at the rounding level -- the oracle
+        itself moves by 8.0e-2 (embeddings, rel-L2) under a 1e-3 relative input perturbation, while its distance to the exact
+        forward (the quantisation noise) is 1.17e-1 -- so elementwise agreement of two implementations is bounded by that
+        noise, not by their arithmetic.  Asserted: the HIP path is no further from the exact forward than 1.5x the oracle's
+        own quantisation noise, and no further from the oracle than that either.  Measured values are printed.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from mst import synth
+
+pytestmark = pytest.mark.gpu
+F8_MAX = 448.0
+GEMM_TOL = 1e-4          # see module docstring
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mst import hip as h
+    h.load()
+    return h
+
+
+def rnd(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g)
+
+
+def deq(b8):
+    return b8.cpu().view(torch.float8_e4m3fn).to(torch.float64)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_quantize_fp8_bit_exact(hip, dt):
+    x = (rnd((1000, 384), 1) * 3).to(dt)
+    x[17, 5] = 100.0          # an outlier sets the scale; most values land in the subnormal / low range of e4m3
+    x[3, 7] = 0.0
+    q, amax = hip.quantize_fp8(x.cuda())
+    assert float(amax) == float(x.float().abs().max())
+    inv = torch.tensor(F8_MAX, dtype=torch.float32) / x.float().abs().max()
+    ref = (x.float() * inv).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), ref)
+    # a caller-supplied floor (calibrated scale) is kept when it is larger than the data
+    floor = torch.full((1,), 1000.0, device="cuda")
+    q2, amax2 = hip.quantize_fp8(x.cuda(), floor)
+    assert float(amax2) == 1000.0
+    ref2 = (x.float() * (torch.tensor(F8_MAX) / 1000.0)).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q2.cpu(), ref2)
+    # all-zero input: scale 0, bytes 0
+    z, az = hip.quantize_fp8(torch.zeros(64, 128, dtype=dt, device="cuda"))
+    assert float(az) == 0.0 and int(z.max()) == 0
+
+
+def _operands(M, N, K, seed):
+    a = rnd((M, K), seed)
+    w = rnd((N, K), seed + 1) / math.sqrt(K)
+    sa, sw = float(a.abs().max()) / F8_MAX, float(w.abs().max()) / F8_MAX
+    a8 = (a / sa).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    w8 = (w / sw).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    return a8, sa, w8, sw
+
+
+def scaled_err(got, ref):
+    ref = ref.double()
+    return float((got.cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 384), (1000, 1152, 384), (257, 384, 1536), (4112, 1536, 384)])
+def test_gemm_fp8_matches_dequantised_product(hip, M, N, K):
+    a8, sa, w8, sw = _operands(M, N, K, 20)
+    bias = rnd((N,), 22) * 0.1
+    amax = torch.tensor([sa * F8_MAX], device="cuda")
+    base = (deq(a8) @ deq(w8).t()) * (sa * sw) + bias.double()
+    ac, wc, bc = a8.cuda(), w8.cuda(), bias.cuda()
+    got = hip.gemm_fp8(ac, amax, wc, sw, bc, out_dtype=torch.float32)
+    assert scaled_err(got, base) < GEMM_TOL
+    got = hip.gemm_fp8(ac, amax, wc, sw, None, out_dtype=torch.float32)
+    assert scaled_err(got, base - bias.double()) < GEMM_TOL
+    ref = base.clone()
+    ref[:, :128] *= 0.125
+    got = hip.gemm_fp8(ac, amax, wc, sw, bc, out_dtype=torch.float32, col_scale=0.125, scale_cols=128)
+    assert scaled_err(got, ref) < GEMM_TOL
+    for odt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 1e-3), (torch.float32, GEMM_TOL)):
+        got = hip.gemm_fp8(ac, amax, wc, sw, bc, epilogue=hip.EPI_BIAS_GELU, out_dtype=odt)
+        assert scaled_err(got, 0.5 * base * (1 + torch.erf(base / math.sqrt(2)))) < tol, odt
+        got = hip.gemm_fp8(ac, amax, wc, sw, bc, epilogue=hip.EPI_BIAS_RELU, out_dtype=odt)
+        assert scaled_err(got, torch.relu(base)) < tol, odt
+    for gamma in (None, rnd((N,), 23) * 0.3 + 1):
+        resid = rnd((M, N), 24)
+        out = resid.cuda().clone()
+        hip.gemm_fp8(ac, amax, wc, sw, bc, epilogue=hip.EPI_RESIDUAL, out=out, gamma=None if gamma is None else gamma.cuda())
+        g = 1.0 if gamma is None else gamma.double()
+        assert scaled_err(out, resid.double() + g * base) < GEMM_TOL
+
+
+def test_gemm_fp8_exact_integers_asymmetric(hip):
+    """A = [I | 0 ...] pattern against an asymmetric small-integer W (all exactly representable in e4m3): exact equality."""
+    M, N, K = 384, 256, 256
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    a[torch.arange(M), (torch.arange(M) * 7 + 3) % K] += 2.0
+    w = (torch.arange(N)[:, None] % 9 - 4) * 1.0 + (torch.arange(K)[None, :] % 5) * 2.0      # -4 .. 12
+    a8 = a.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    w8 = w.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    amax = torch.tensor([F8_MAX], device="cuda")                                             # scale 1
+    got = hip.gemm_fp8(a8, amax, w8, 1.0, None, out_dtype=torch.float32)
+    assert torch.equal(got.cpu(), a @ w.t())
+
+
+def test_gemm_fp8_argument_errors(hip):
+    a8 = torch.zeros(64, 100, dtype=torch.uint8, device="cuda")
+    w8 = torch.zeros(128, 100, dtype=torch.uint8, device="cuda")
+    amax = torch.ones(1, device="cuda")
+    with pytest.raises(RuntimeError, match="K=100"):
+        hip.gemm_fp8(a8, amax, w8, 1.0, None)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        hip.quantize_fp8(torch.zeros(7, dtype=torch.bfloat16, device="cuda"))
+
+
+def _model(mode, seed=0):
+    from mst.models import DinoV2ClassifierSlice
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode)
+    sd = synth.synth_state_dict("s", seed)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval(), sd
+
+
+def test_fp8_single_block_against_oracle():
+    """Depth-1 encoder: identical inputs reach the four e4m3 GEMMs of the block, so the result is tight."""
+    from oracle import mst_oracle as O
+    from mst.models import DinoV2ClassifierSlice
+    from mst.models.dino import _ViT
+    sd = {k: v for k, v in synth.synth_state_dict("s", 4).items()
+          if not (k.startswith("encoder.blocks.0.") and k.split(".")[3] != "0")}
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8")
+    model.encoder = _ViT(384, 1, 6)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    O.VIT_CFG["s_depth1"] = dict(embed_dim=384, depth=1, num_heads=6)
+    src = synth.synth_volume((1, 1, 6, 112, 112), 8)
+    try:
+        with torch.no_grad():
+            emb, _, _ = model.encode_slices(src.cuda().reshape(6, 112, 112))
+            ref8, _ = O.vit_encode(sd, src.reshape(6, 112, 112), "s_depth1", linear="fp8")
+            ref, _ = O.vit_encode(sd, src.reshape(6, 112, 112), "s_depth1")
+    finally:
+        del O.VIT_CFG["s_depth1"]
+    e8, q = rel_l2(emb.cpu(), ref8), rel_l2(ref8, ref)
+    print(f"fp8 one block: emb rel-L2 vs fp8 oracle {e8:.3e}; quantisation noise of the block (oracle fp8 vs exact) {q:.3e}")
+    assert e8 < 0.75 * q
+
+
+def test_fp8_forward_against_oracle():
+    from oracle import mst_oracle as O
+    model, sd = _model("fp8")
+    src = synth.synth_volume((1, 1, 16, 224, 224), 0)
+    with torch.no_grad():
+        logits = model(src, save_attn=True)
+        emb, _, _ = model.encode_slices(src.cuda().reshape(16, 224, 224))
+        ref8 = O.forward(sd, src, keep="cls", linear="fp8")
+        ref = O.forward(sd, src, keep="cls")
+    lg = logits.cpu()
+    d8, dx, dq = (float((lg - ref8["logits"]).abs().max()), float((lg - ref["logits"]).abs().max()),
+                  float((ref8["logits"] - ref["logits"]).abs().max()))
+    e8, ex, eq = rel_l2(emb.cpu(), ref8["emb"]), rel_l2(emb.cpu(), ref["emb"]), rel_l2(ref8["emb"], ref["emb"])
+    am, am8, amx = (model.get_attention_maps().cpu(), O.attention_maps(ref8["vit_maps"][-1], ref8["slice_map"]),
+                    O.attention_maps(ref["vit_maps"][-1], ref["slice_map"]))
+    m8, mx, mq = rel_l2(am, am8), rel_l2(am, amx), rel_l2(am8, amx)
+    print(f"fp8 forward (HIP vs fp8 oracle / HIP vs exact / fp8 oracle vs exact): logits {d8:.3e} / {dx:.3e} / {dq:.3e}; "
+          f"emb rel-L2 {e8:.3e} / {ex:.3e} / {eq:.3e}; maps rel-L2 {m8:.3e} / {mx:.3e} / {mq:.3e}")
+    assert ex < 1.5 * eq and e8 < 1.5 * eq
+    assert mx < 1.5 * mq and m8 < 1.5 * mq
+    assert dx < 2.0 * dq + 3e-2 and d8 < 2.0 * dq + 3e-2          # + the bf16 mode's own logits tolerance
+    assert abs(float(am.sum()) - 6) < 1e-2                        # maps stay normalised (heads x 1)
+
+
+def test_fp8_mode_is_deterministic():
+    model, _ = _model("fp8", seed=3)
+    src = synth.synth_volume((1, 1, 8, 112, 112), 5)
+    with torch.no_grad():
+        a = model(src).clone()
+        b = model(src).clone()
+    assert torch.equal(a, b)

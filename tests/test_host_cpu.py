@@ -125,3 +125,27 @@ def test_slice_sharding_all_gather_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_oracle_fp8_linear_properties():
+    """oracle fp8_linear (BASELINE configs[4] arithmetic; no reference code exists for it): exact when both operands are
+    representable in e4m3 at the absmax scale, bounded relative error otherwise, zero input handled."""
+    import torch
+    from oracle import mst_oracle as O
+    g = torch.Generator().manual_seed(0)
+    # integers up to 16 with max 448 -> scale 1: exactly representable
+    x = torch.randint(-8, 9, (5, 64), generator=g).float()
+    x[0, 0] = 448.0
+    w = torch.randint(-4, 5, (7, 64), generator=g).float()
+    w[0, 0] = 448.0
+    b = torch.randn(7, generator=g)
+    assert torch.allclose(O.fp8_linear(x, w, b), torch.nn.functional.linear(x, w, b), rtol=0, atol=1e-4)
+    # random operands: e4m3 keeps 3 mantissa bits -> per-element relative error <= 2^-4, result error a few % of the scale
+    x, w = torch.randn(64, 384, generator=g), torch.randn(128, 384, generator=g) / 384 ** 0.5
+    y, r = O.fp8_linear(x, w, None), torch.nn.functional.linear(x, w)
+    assert 1e-3 < float((y - r).norm() / r.norm()) < 6e-2
+    q, s = O.fp8_e4m3(x)
+    assert float(q.abs().max()) == 448.0 and abs(s * 448.0 - float(x.abs().max())) < 1e-6
+    assert float((q * s - x).abs().max()) <= float(x.abs().max()) / 16 + 1e-6
+    z, _ = O.fp8_e4m3(torch.zeros(4, 8))
+    assert float(z.abs().max()) == 0.0
