@@ -41,8 +41,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)v[j]));
     }
+    // one atomic per workgroup, and only when it can raise the running maximum (a stale read is merely too small): thousands of
+    // same-address atomics serialise in one L2 channel -- the first version spent more time there than reading the tensor
+    __shared__ float wmax[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > __uint_as_float(*(volatile unsigned int*)amax_bits)) atomicMax(amax_bits, __float_as_uint(m));
+    }
 }
 
 __device__ __forceinline__ float f8_inv_scale(float amax) { return amax > 0.f ? F8_MAX / amax : 0.f; }
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
                                                     int64_t ldw, const float* __restrict__ bias,
                                                     const float* __restrict__ a_amax, float w_scale, OutT* C, int64_t ldc,
                                                     int M, int N, int K, const float* __restrict__ gamma, float col_scale,
-                                                    int scale_cols, int tiles_n, int nwg) {
+                                                    int scale_cols, int tiles_n, int nwg, float* out_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const As = smem;                   // [2][128 rows][128 B]
     char* const Ws = smem + 2 * TILE_BYTES;
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
 
     // epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*64+i*16+(lane>>4)*4
     const float dq = (*a_amax) * (1.0f / F8_MAX) * w_scale;
+    float omax = 0.f;   // max |C as stored| of this lane (16-bit outputs feeding the next e4m3 GEMM)
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -212,17 +221,26 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
                     pk[2] = (OutT)v[2];
                     pk[3] = (OutT)v[3];
                     *reinterpret_cast<o4*>(cp) = pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) omax = fmaxf(omax, fabsf((float)pk[r]));
                 }
             }
         }
     };
     if (m0 + BM <= M) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    if constexpr (sizeof(OutT) == 2) {
+        if (out_amax) {
+            omax = wave_max(omax);
+            if (lane == 0 && omax > *(volatile float*)out_amax) atomicMax((unsigned int*)out_amax, __float_as_uint(omax));
+        }
+    }
 }
 
 template <int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* a_amax, float w_scale,
-             void* C, int64_t ldc, int64_t M, int N, int K, const float* gamma, float cs, int sc, hipStream_t s) {
+             void* C, int64_t ldc, int64_t M, int N, int K, const float* gamma, float cs, int sc, float* out_amax,
+             hipStream_t s) {
     static mst_lds_once lds_once[2];
     static const bool mx = !(getenv("MST_FP8_MX") && atoi(getenv("MST_FP8_MX")) == 0);
     auto kern = mx ? gemm8_kernel<EPI, OutT, true> : gemm8_kernel<EPI, OutT, false>;
@@ -230,20 +248,21 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int nwg = tiles_m * tiles_n;
     kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const uint8_t*)A, lda, (const uint8_t*)W, ldw, bias, a_amax, w_scale,
-                                                       (OutT*)C, ldc, (int)M, N, K, gamma, cs, sc, tiles_n, nwg);
+                                                       (OutT*)C, ldc, (int)M, N, K, gamma, cs, sc, tiles_n, nwg, out_amax);
     return mst_check_launch("gemm8");
 }
 
 template <typename OutT>
 int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* a_amax, float w_scale,
-             void* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float cs, int sc, hipStream_t s) {
+             void* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float cs, int sc, float* out_amax,
+             hipStream_t s) {
     switch (epi) {
         case MST_EPI_BIAS:
-            return launch_t<MST_EPI_BIAS, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, s);
+            return launch_t<MST_EPI_BIAS, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
         case MST_EPI_BIAS_GELU:
-            return launch_t<MST_EPI_BIAS_GELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, s);
+            return launch_t<MST_EPI_BIAS_GELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
         case MST_EPI_BIAS_RELU:
-            return launch_t<MST_EPI_BIAS_RELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, s);
+            return launch_t<MST_EPI_BIAS_RELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
     }
     mst_set_error("gemm8: bad epilogue %d", epi);
     return MST_EINVAL;
@@ -251,7 +270,7 @@ int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float
 
 }  // namespace
 
-int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, hipStream_t s) {
+int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s) {
     MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "quantize_fp8: input dtype %d must be bf16 or fp16", dt);
     MST_CHECK_ARG(n >= 0 && n % 8 == 0, "quantize_fp8: n=%lld must be a multiple of 8", (long long)n);
     if (n == 0) return MST_OK;
@@ -259,10 +278,10 @@ int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, hip
     const int64_t want = (n8 + 255) / 256;
     const int grid = (int)(want < 4096 ? want : 4096);
     if (dt == MST_BF16) {
-        absmax_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, (unsigned int*)amax);
+        if (scan) absmax_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, (unsigned int*)amax);
         quant8_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, amax, (uint8_t*)out8);
     } else {
-        absmax_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, (unsigned int*)amax);
+        if (scan) absmax_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, (unsigned int*)amax);
         quant8_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, amax, (uint8_t*)out8);
     }
     return mst_check_launch("quantize_fp8");
@@ -270,8 +289,9 @@ int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, hip
 
 int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
-                 float col_scale, int scale_cols, hipStream_t s) {
+                 float col_scale, int scale_cols, float* out_amax, hipStream_t s) {
     MST_CHECK_ARG(A8 && W8 && C && a_amax, "gemm8: null pointer");
+    MST_CHECK_ARG(!out_amax || (cdt != MST_F32 && epi != MST_EPI_RESIDUAL), "gemm8: out_amax needs a 16-bit, non-residual C");
     MST_CHECK_ARG(K > 0 && K % BKB == 0, "gemm8: K=%d must be a multiple of %d", K, BKB);
     MST_CHECK_ARG(N > 0 && N % BN == 0, "gemm8: N=%d must be a multiple of %d", N, BN);
     MST_CHECK_ARG(lda % 16 == 0 && ldw % 16 == 0 && ldc % 4 == 0, "gemm8: lda/ldw must be multiples of 16, ldc of 4");
@@ -281,8 +301,8 @@ int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const
     if (M <= 0) return MST_OK;
     if (epi == MST_EPI_RESIDUAL)
         return launch_t<MST_EPI_RESIDUAL, float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, col_scale,
-                                                 scale_cols, s);
-    if (cdt == MST_F32) return dispatch<float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
-    if (cdt == MST_BF16) return dispatch<bf16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
-    return dispatch<f16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
+                                                 scale_cols, nullptr, s);
+    if (cdt == MST_F32) return dispatch<float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
+    if (cdt == MST_BF16) return dispatch<bf16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
+    return dispatch<f16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
 }

@@ -113,14 +113,14 @@ int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ld
 
 int mst_quantize_fp8(const void* x, int dtype, int64_t n, float* amax, void* out8, mst_stream_t stream) {
     MST_CHECK_ARG(x && amax && out8, "quantize_fp8: null pointer");
-    return launch_quant8(x, dtype, n, amax, out8, (hipStream_t)stream);
+    return launch_quant8(x, dtype, n, amax, out8, 1, (hipStream_t)stream);
 }
 
 int mst_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
                  const float* gamma, float col_scale, int scale_cols, mst_stream_t stream) {
     return launch_gemm8(A8, lda, W8, ldw, bias, a_amax, w_scale, C, c_dtype, ldc, M, N, K, epilogue, gamma, col_scale,
-                        scale_cols, (hipStream_t)stream);
+                        scale_cols, nullptr, (hipStream_t)stream);
 }
 
 int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, void* out,
@@ -272,11 +272,13 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             const mst_vit_layer* L = &w->layers[l];
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
             if (fp8) {
-                // every linear layer: quantise its input with a fresh per-tensor scale (this chunk's max|x|), e4m3 GEMM
+                // every linear layer: quantise its input with a fresh per-tensor scale (this chunk's max|x|), e4m3 GEMM.  The
+                // producers that this file owns keep the running maximum of what they store (LayerNorm, the GELU epilogue), so
+                // only the attention output needs a scan of its own
                 float* am = amax + l * 4;
-                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
-                RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, s));
-                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm_amax(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, am + 0, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, 0, s));
+                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, s));
             } else if (fused) {
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             } else {
@@ -292,13 +294,13 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
             if (fp8) {
                 float* am = amax + l * 4;
-                RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, s));
-                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
-                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
-                RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, s));
-                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
-                RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, s));
-                RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, 1, s));
+                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm_amax(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, am + 2, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, 0, s));
+                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, s));
+                RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, 0, s));
+                RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, s));
                 continue;
             }
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
