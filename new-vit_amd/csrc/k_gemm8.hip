@@ -230,9 +230,16 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
     if (m0 + BM <= M) epilogue(std::true_type{});
     else epilogue(std::false_type{});
     if constexpr (sizeof(OutT) == 2) {
-        if (out_amax) {
+        if (out_amax) {   // uniform.  One poll of the running maximum per workgroup: polls of one address serialise in an L2 channel
+            float* red = reinterpret_cast<float*>(smem);
             omax = wave_max(omax);
-            if (lane == 0 && omax > *(volatile float*)out_amax) atomicMax((unsigned int*)out_amax, __float_as_uint(omax));
+            __syncthreads();   // every wave is done with the operand tiles
+            if (lane == 0) red[wave] = omax;
+            __syncthreads();
+            if (tid == 0) {
+                omax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                if (omax > *(volatile float*)out_amax) atomicMax((unsigned int*)out_amax, __float_as_uint(omax));
+            }
         }
     }
 }

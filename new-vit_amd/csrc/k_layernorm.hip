@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g,
                                                         const float* __restrict__ b,
                                                         OutT* __restrict__ out, int64_t os,
-                                                        int64_t rows, int cols, float eps, float* amax) {
+                                                        int64_t rows, int cols, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -40,7 +40,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
     OutT* orow = out + row * os;
-    float am = 0.f;   // max |output as stored| of this row (fp8 mode: the per-tensor scale of the following GEMM input)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int c = j * 128 + lane * 2;
@@ -60,45 +59,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 pk[0] = (OutT)y0;
                 pk[1] = (OutT)y1;
                 *reinterpret_cast<o2*>(orow + c) = pk;
-                am = fmaxf(am, fmaxf(fabsf((float)pk[0]), fabsf((float)pk[1])));
             }
         }
-    }
-    if (amax) {   // uniform branch.  A stale read can only be too small -> one redundant atomic, never a lost maximum
-        am = wave_max(am);
-        if (lane == 0 && am > *(volatile float*)amax) atomicMax((unsigned int*)amax, __float_as_uint(am));
     }
 }
 
 template <typename OutT>
 static int launch_ln_t(const float* x, int64_t xs, const float* g, const float* b, void* out, int64_t os,
-                       int64_t rows, int cols, float eps, float* amax, hipStream_t s) {
+                       int64_t rows, int cols, float eps, hipStream_t s) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const int nj = (cols + 127) / 128;
     OutT* o = (OutT*)out;
-    if (nj <= 1) layernorm_kernel<1, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps, amax);
-    else if (nj <= 3) layernorm_kernel<3, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps, amax);
-    else if (nj <= 6) layernorm_kernel<6, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps, amax);
-    else layernorm_kernel<8, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps, amax);
+    if (nj <= 1) layernorm_kernel<1, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else if (nj <= 3) layernorm_kernel<3, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else if (nj <= 6) layernorm_kernel<6, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else layernorm_kernel<8, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
     return mst_check_launch("layernorm");
 }
 
 int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
                      int64_t os, int64_t rows, int cols, float eps, hipStream_t s) {
-    return launch_layernorm_amax(x, xs, g, b, out, odt, os, rows, cols, eps, nullptr, s);
-}
-
-// amax (nullable, 16-bit outputs only): *amax = max(*amax, max |out|) over the values as stored
-int launch_layernorm_amax(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt, int64_t os,
-                          int64_t rows, int cols, float eps, float* amax, hipStream_t s) {
-    MST_CHECK_ARG(!amax || odt != MST_F32, "layernorm: amax output needs a 16-bit out dtype");
     MST_CHECK_ARG(cols > 0 && cols <= 1024 && (cols % 2) == 0, "layernorm: cols=%d must be even and <= 1024", cols);
     MST_CHECK_ARG((xs % 2) == 0 && (os % 2) == 0, "layernorm: row strides must be even");
     if (rows <= 0) return MST_OK;
     switch (odt) {
-        case MST_F32: return launch_ln_t<float>(x, xs, g, b, out, os, rows, cols, eps, amax, s);
-        case MST_F16: return launch_ln_t<f16_t>(x, xs, g, b, out, os, rows, cols, eps, amax, s);
-        case MST_BF16: return launch_ln_t<bf16_t>(x, xs, g, b, out, os, rows, cols, eps, amax, s);
+        case MST_F32: return launch_ln_t<float>(x, xs, g, b, out, os, rows, cols, eps, s);
+        case MST_F16: return launch_ln_t<f16_t>(x, xs, g, b, out, os, rows, cols, eps, s);
+        case MST_BF16: return launch_ln_t<bf16_t>(x, xs, g, b, out, os, rows, cols, eps, s);
     }
     mst_set_error("layernorm: bad out dtype %d", odt);
     return MST_EINVAL;

@@ -273,11 +273,12 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
             if (fp8) {
                 // every linear layer: quantise its input with a fresh per-tensor scale (this chunk's max|x|), e4m3 GEMM.  The
-                // producers that this file owns keep the running maximum of what they store (LayerNorm, the GELU epilogue), so
-                // only the attention output needs a scan of its own
+                // [M,E] inputs are scanned (53 us; a running maximum kept by the one-wave-per-row LayerNorm kernel cost 125 us:
+                // 350 k waves polling one address serialise in one L2 channel); the 4x larger hidden activation gets its maximum
+                // from the fc1 epilogue (one conditional atomic per workgroup)
                 float* am = amax + l * 4;
-                RUNK(MST_K_LAYERNORM, launch_layernorm_amax(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, am + 0, s));
-                RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, 0, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, 1, s));
                 RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, s));
             } else if (fused) {
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
@@ -296,8 +297,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 float* am = amax + l * 4;
                 RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, 1, s));
                 RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, s));
-                RUNK(MST_K_LAYERNORM, launch_layernorm_amax(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, am + 2, s));
-                RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, 0, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
+                RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, 1, s));
                 RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, s));
                 RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, 0, s));
                 RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, s));

@@ -163,8 +163,6 @@ int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, cons
 bool gemm32_small_applicable(int64_t M, int N, int K);
 int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                         int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols, hipStream_t s);
-int launch_layernorm_amax(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt, int64_t os,
-                          int64_t rows, int cols, float eps, float* amax, hipStream_t s);
 // scan: 1 = *amax = max(*amax, max|x|) first (one extra pass over x); 0 = *amax already covers x (its producer kept it)
 int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s);
 // out_amax (nullable, 16-bit C, non-residual epilogues): *out_amax = max(*out_amax, max |C as stored|)
