@@ -200,3 +200,36 @@ def test_fp8_mode_is_deterministic():
         a = model(src).clone()
         b = model(src).clone()
     assert torch.equal(a, b)
+
+
+def test_fp8_forward_is_hipgraph_capturable_and_chunk_scales_are_per_pass():
+    """The dynamic scales never visit the host (hipMemsetAsync + device atomics), so the fp8 forward captures into a hipGraph
+    like the other modes.  Scales are per encoder pass: chunking changes them, so chunked fp8 results differ slightly from
+    unchunked ones (documented in include/mst_hip.h) but stay within the quantisation noise."""
+    model, _ = _model("fp8", seed=2)
+    src = synth.synth_volume((1, 1, 8, 112, 112), 6).cuda()
+    with torch.no_grad():
+        eager = model(src).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(src)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        from mst.models import DinoV2ClassifierSlice
+
+        def emb(mode, **kw):
+            m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode, **kw)
+            m.load_state_dict(synth.synth_state_dict("s", 2), strict=True)
+            return m.cuda().eval().encode_slices(src.reshape(8, 112, 112))[0].cpu()
+
+        exact, whole, chunked = emb("fp32"), emb("fp8"), emb("fp8", chunk_slices=3)
+    # measured: 0.164 (one pass) and 0.162 (passes of 3, 3, 2 slices) from the exact embeddings, 0.121 from each other
+    nw, nc = rel_l2(whole, exact), rel_l2(chunked, exact)
+    assert not torch.equal(whole, chunked)
+    assert nc < 1.25 * nw and rel_l2(chunked, whole) < 1.5 * nw
