@@ -149,3 +149,23 @@ def test_oracle_fp8_linear_properties():
     assert float((q * s - x).abs().max()) <= float(x.abs().max()) / 16 + 1e-6
     z, _ = O.fp8_e4m3(torch.zeros(4, 8))
     assert float(z.abs().max()) == 0.0
+
+
+def test_fp8_weight_quantisation_host_side():
+    """hip.quantize_weight_fp8 (host-side weight preparation of compute_dtype='fp8'): bytes are torch's e4m3fn encoding,
+    scale = max|W|/448, the largest weight maps to +-448 exactly and dequantisation stays within one e4m3 step."""
+    import torch
+    from mst import hip
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(96, 384, generator=g) * 0.03
+    q8, scale = hip.quantize_weight_fp8(w)
+    assert q8.dtype == torch.uint8 and q8.shape == w.shape and q8.is_contiguous()
+    assert abs(scale - float(w.abs().max()) / 448.0) < 1e-9
+    deq = q8.view(torch.float8_e4m3fn).float() * scale
+    assert float(deq.abs().max()) == pytest.approx(float(w.abs().max()), rel=1e-6)
+    # normal range: relative step 2^-4 (half-step error after rounding); subnormals: absolute step 2^-9 * scale
+    err = (deq - w).abs()
+    assert bool((err <= w.abs() / 16 + 2.0 ** -10 * scale + 1e-12).all())
+    z8, zs = hip.quantize_weight_fp8(torch.zeros(8, 16))
+    assert int(z8.max()) == 0 and zs == 1.0
+    assert "fp8" in hip.DT_NAMES and hip.DT_NAMES["fp8"] == hip.BF16 and "fp8" in hip.FP8_NAMES
