@@ -95,14 +95,14 @@ def test_shard_range_covers_all_slices():
             assert got == list(range(D))
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, D=7):
     import torch.distributed as dist
     sys.path.insert(0, str(ROOT / "new-vit_amd"))
     from mst.parallel import SliceSharding
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         sh = SliceSharding()
-        B, D, X = 3, 7, 5                                      # D not divisible by the world size
+        B, X = 3, 5                                            # D = 7: not divisible by the world size
         full = torch.arange(B * D * X, dtype=torch.float32).reshape(B, D, X)
         d0, d1, dpad = sh.shard_range(D)
         local = torch.zeros(B, dpad, X)
@@ -125,6 +125,22 @@ def test_slice_sharding_all_gather_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("D", [7, 3])
+def test_slice_sharding_all_gather_gloo_world4_uneven_and_empty_shards(D):
+    """Four ranks: D = 7 leaves the last rank one slice of its two-slice shard, D = 3 leaves it none (empty shard, all padding)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + D
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 4, port, q, D)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(4)]
 
 
 def test_oracle_fp8_linear_properties():
