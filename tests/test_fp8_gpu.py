@@ -233,3 +233,36 @@ def test_fp8_forward_is_hipgraph_capturable_and_chunk_scales_are_per_pass():
     nw, nc = rel_l2(whole, exact), rel_l2(chunked, exact)
     assert not torch.equal(whole, chunked)
     assert nc < 1.25 * nw and rel_l2(chunked, whole) < 1.5 * nw
+
+
+def _noise_check(model, sd, src, model_size="s", regs=0):
+    """HIP fp8 embeddings vs the exact oracle and vs the fp8 oracle, both within 1.5x the oracle's own quantisation noise."""
+    from oracle import mst_oracle as O
+    n, H, W = src.shape[0] * src.shape[2], src.shape[3], src.shape[4]
+    with torch.no_grad():
+        emb = model.encode_slices(src.cuda().reshape(n, H, W))[0].cpu()
+        ref8, _ = O.vit_encode(sd, src.reshape(n, H, W), model_size, linear="fp8")
+        ref, _ = O.vit_encode(sd, src.reshape(n, H, W), model_size)
+    e8, ex, eq = rel_l2(emb, ref8), rel_l2(emb, ref), rel_l2(ref8, ref)
+    print(f"fp8 {model_size} regs={regs}: emb rel-L2 HIP-fp8oracle {e8:.3e}, HIP-exact {ex:.3e}, fp8oracle-exact {eq:.3e}")
+    assert ex < 1.5 * eq and e8 < 1.5 * eq
+
+
+def test_fp8_vit_base_width():
+    """E = 768, 12 heads: other K / N tile counts of the e4m3 GEMMs (6 k-stages; 18, 6, 24 column tiles)."""
+    from mst.models import DinoV2ClassifierSlice
+    sd = synth.synth_state_dict("b", 6)
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8", model_size="b")
+    model.load_state_dict(sd, strict=True)
+    _noise_check(model.cuda().eval(), sd, synth.synth_volume((1, 1, 3, 112, 84), 12), "b")
+
+
+def test_fp8_hub_layout_layerscale_registers():
+    """LayerScale gammas ride on the e4m3 GEMMs' residual epilogue; 4 register tokens; 518-grid position table resampled."""
+    from mst.models import DinoV2ClassifierSlice
+    from mst.models.dino import _ViT
+    sd = synth.synth_state_dict("s", 9, img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8", use_registers=True)
+    model.encoder = _ViT(384, 12, 6, img_size=518, num_register_tokens=4, layerscale=1.0, chunked=False)
+    model.load_state_dict(sd, strict=True)
+    _noise_check(model.cuda().eval(), sd, synth.synth_volume((1, 1, 3, 70, 98), 21), "s", regs=4)
