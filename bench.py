@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--parallelism", default="slice", choices=["slice", "dp"],
                     help="N > 1: 'slice' = slices of every volume sharded over the ranks + one all-gather (north star, default); "
                          "'dp' = whole volumes per rank, no exchange at all (SURVEY 8e: the better choice when B >= N)")
+    ap.add_argument("--fp8-calibrate", action="store_true",
+                    help="--dtype fp8 only: calibrate static activation scales on the bench batch first (untimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -131,6 +133,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.fp8_calibrate:
+        if args.dtype != "fp8":
+            raise SystemExit("--fp8-calibrate needs --dtype fp8")
+        model.calibrate_fp8(vol)
     with torch.no_grad():
         for _ in range(args.warmup):
             out = model(vol)
@@ -222,7 +228,7 @@ def main():
             "metric": "volumes_per_sec_mst_dinov2_fwd", "value": round(value, 3), "unit": "volumes/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + ("-calibrated" if args.fp8_calibrate else ""), "data": "synthetic",
             "config": {"workload": f"MST-DINOv2 (DinoV2ClassifierSlice, ViT-S/14) forward, {Bl} volumes/GPU of "
                                    f"{D}x{args.size}x{args.size} {args.dtype} zero-padded to {side}x{side} (N={N} tokens/slice)",
                        "global_batch_volumes": B, "slices": D, "in_plane": [side, side],

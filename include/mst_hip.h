@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* mst_stream_t; /* hipStream_t */
 
-enum mst_dtype { MST_F32 = 0, MST_F16 = 1, MST_BF16 = 2 };
+enum mst_dtype { MST_F32 = 0, MST_F16 = 1, MST_BF16 = 2, MST_F8E4M3 = 3 /* OCP e4m3 bytes: fp8 entry points only */ };
 
 enum mst_status {
     MST_OK = 0,
@@ -80,11 +80,15 @@ int mst_gemm(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ld
  *   host synchronisation.
  * mst_gemm_fp8: C[M,N] = epi((*a_amax/448 * w_scale) * A8[M,K] . W8[N,K]^T + bias); A8, W8 e4m3 bytes with K-contiguous
  *   rows; K % 128 == 0, N % 128 == 0, lda/ldw % 16 == 0; c_dtype f32 / bf16 / fp16; epilogues, gamma, col_scale and
- *   scale_cols as mst_gemm. */
+ *   scale_cols as mst_gemm.  c_dtype MST_F8E4M3 (non-residual epilogues): C is written as e4m3 bytes rne(clamp(v * 448 /
+ *   *c_amax)) under the caller's scale c_amax (device fp32; calibrated: nothing is scanned); c_amax is ignored otherwise.
+ * mst_layernorm_fp8: mst_layernorm writing e4m3 bytes under a calibrated scale: out8 = rne(clamp(LN(x) * 448 / *amax)). */
 int mst_quantize_fp8(const void* x, int dtype, int64_t n, float* amax, void* out8, mst_stream_t stream);
 int mst_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
-                 const float* gamma, float col_scale, int scale_cols, mst_stream_t stream);
+                 const float* gamma, float col_scale, int scale_cols, const float* c_amax, mst_stream_t stream);
+int mst_layernorm_fp8(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out8,
+                      int64_t out_stride, int64_t rows, int cols, float eps, const float* amax, mst_stream_t stream);
 
 /* softmax(q k^T) v per (sequence, head), q pre-scaled: attention.py:56-66 (== xformers
  * memory_efficient_attention, attention.py:84).  qkv [n_seq*N, 3*heads*head_dim] packed as the
@@ -170,6 +174,11 @@ typedef struct mst_vit_weights {
     int fp8_linear;               /* 1: the blocks' four linear layers run as mst_gemm_fp8 with dynamic per-tensor activation
                                    * scales (one per GEMM call, i.e. per chunk of slices); needs a 16-bit compute_dtype, which
                                    * stays the type of LayerNorm outputs, q/k/v and the attention kernel */
+    const float* fp8_amax;        /* NULL: dynamic scales.  Else device fp32 [depth][4] = calibrated max|x| of the inputs of
+                                   * qkv, proj, fc1, fc2 per block (static scales; larger values saturate at +-448 quanta): LayerNorm
+                                   * and the GELU epilogue then write e4m3 directly and nothing is scanned */
+    float* fp8_amax_out;          /* dynamic mode, nullable: device fp32 [depth][4], out[i] = max(out[i], this call's scales):
+                                   * zero it, run representative inputs, and pass it back as fp8_amax (calibration) */
 } mst_vit_weights;
 
 /* DinoVisionTransformer.forward on n_slices gray slices (vision_transformer.py:254-270,324-329;

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
                                                     int64_t ldw, const float* __restrict__ bias,
                                                     const float* __restrict__ a_amax, float w_scale, OutT* C, int64_t ldc,
                                                     int M, int N, int K, const float* __restrict__ gamma, float col_scale,
-                                                    int scale_cols, int tiles_n, int nwg, float* out_amax) {
+                                                    int scale_cols, int tiles_n, int nwg, float* out_amax,
+                                                    const float* __restrict__ c_amax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const As = smem;                   // [2][128 rows][128 B]
     char* const Ws = smem + 2 * TILE_BYTES;
@@ -178,6 +179,8 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
     // epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*64+i*16+(lane>>4)*4
     const float dq = (*a_amax) * (1.0f / F8_MAX) * w_scale;
     float omax = 0.f;   // max |C as stored| of this lane (16-bit outputs feeding the next e4m3 GEMM)
+    float cq = 0.f;     // e4m3 output: quanta per unit under the caller's calibrated scale
+    if constexpr (sizeof(OutT) == 1) cq = f8_inv_scale(*c_amax);
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = fmaf(acc[i][j][r], dq, bb[r]) * sc[r];
-                    if (EPI == MST_EPI_BIAS_GELU) v[r] = (sizeof(OutT) == 2) ? gelu_fast(v[r]) : gelu_erf(v[r]);
+                    if (EPI == MST_EPI_BIAS_GELU) v[r] = (sizeof(OutT) <= 2) ? gelu_fast(v[r]) : gelu_erf(v[r]);
                     if (EPI == MST_EPI_BIAS_RELU) v[r] = fmaxf(v[r], 0.f);
                 }
                 OutT* cp = C + (int64_t)m * ldc + n;
@@ -213,6 +216,13 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
                     *reinterpret_cast<float4*>(cp) = o;
                 } else if constexpr (sizeof(OutT) == 4) {
                     *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (sizeof(OutT) == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r] * cq, -F8_MAX, F8_MAX);
+                    int pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                    *reinterpret_cast<int*>(cp) = pk;
                 } else {
                     typedef __attribute__((ext_vector_type(4))) OutT o4;
                     o4 pk;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm8_kernel(const uint8_t* __restrict__ 
 template <int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* a_amax, float w_scale,
              void* C, int64_t ldc, int64_t M, int N, int K, const float* gamma, float cs, int sc, float* out_amax,
-             hipStream_t s) {
+             const float* c_amax, hipStream_t s) {
     static mst_lds_once lds_once[2];
     static const bool mx = !(getenv("MST_FP8_MX") && atoi(getenv("MST_FP8_MX")) == 0);
     auto kern = mx ? gemm8_kernel<EPI, OutT, true> : gemm8_kernel<EPI, OutT, false>;
@@ -255,27 +265,38 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int nwg = tiles_m * tiles_n;
     kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const uint8_t*)A, lda, (const uint8_t*)W, ldw, bias, a_amax, w_scale,
-                                                       (OutT*)C, ldc, (int)M, N, K, gamma, cs, sc, tiles_n, nwg, out_amax);
+                                                       (OutT*)C, ldc, (int)M, N, K, gamma, cs, sc, tiles_n, nwg, out_amax, c_amax);
     return mst_check_launch("gemm8");
 }
 
 template <typename OutT>
 int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* a_amax, float w_scale,
              void* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float cs, int sc, float* out_amax,
-             hipStream_t s) {
+             const float* c_amax, hipStream_t s) {
     switch (epi) {
         case MST_EPI_BIAS:
-            return launch_t<MST_EPI_BIAS, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
+            return launch_t<MST_EPI_BIAS, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, c_amax, s);
         case MST_EPI_BIAS_GELU:
-            return launch_t<MST_EPI_BIAS_GELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
+            return launch_t<MST_EPI_BIAS_GELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, c_amax, s);
         case MST_EPI_BIAS_RELU:
-            return launch_t<MST_EPI_BIAS_RELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, s);
+            return launch_t<MST_EPI_BIAS_RELU, OutT>(A, lda, W, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, cs, sc, out_amax, c_amax, s);
     }
     mst_set_error("gemm8: bad epilogue %d", epi);
     return MST_EINVAL;
 }
 
 }  // namespace
+
+__global__ void amax_merge_kernel(float* out, const float* in, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fmaxf(out[i], in[i]);
+}
+
+int launch_amax_merge(float* out, const float* in, int n, hipStream_t s) {
+    if (n <= 0) return MST_OK;
+    amax_merge_kernel<<<(n + 63) / 64, 64, 0, s>>>(out, in, n);
+    return mst_check_launch("amax_merge");
+}
 
 int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s) {
     MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "quantize_fp8: input dtype %d must be bf16 or fp16", dt);
@@ -296,20 +317,23 @@ int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int
 
 int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
-                 float col_scale, int scale_cols, float* out_amax, hipStream_t s) {
+                 float col_scale, int scale_cols, float* out_amax, const float* c_amax, hipStream_t s) {
     MST_CHECK_ARG(A8 && W8 && C && a_amax, "gemm8: null pointer");
+    MST_CHECK_ARG(cdt != MST_F8E4M3 || (c_amax && epi != MST_EPI_RESIDUAL && !out_amax),
+                  "gemm8: an e4m3 C needs c_amax and a non-residual epilogue");
     MST_CHECK_ARG(!out_amax || (cdt != MST_F32 && epi != MST_EPI_RESIDUAL), "gemm8: out_amax needs a 16-bit, non-residual C");
     MST_CHECK_ARG(K > 0 && K % BKB == 0, "gemm8: K=%d must be a multiple of %d", K, BKB);
     MST_CHECK_ARG(N > 0 && N % BN == 0, "gemm8: N=%d must be a multiple of %d", N, BN);
     MST_CHECK_ARG(lda % 16 == 0 && ldw % 16 == 0 && ldc % 4 == 0, "gemm8: lda/ldw must be multiples of 16, ldc of 4");
     MST_CHECK_ARG(M < (1ll << 31) - BM, "gemm8: M too large");
-    MST_CHECK_ARG(cdt == MST_F32 || cdt == MST_BF16 || cdt == MST_F16, "gemm8: bad C dtype %d", cdt);
+    MST_CHECK_ARG(cdt == MST_F32 || cdt == MST_BF16 || cdt == MST_F16 || cdt == MST_F8E4M3, "gemm8: bad C dtype %d", cdt);
     MST_CHECK_ARG(epi != MST_EPI_RESIDUAL || cdt == MST_F32, "gemm8: residual epilogue needs f32 C");
     if (M <= 0) return MST_OK;
     if (epi == MST_EPI_RESIDUAL)
         return launch_t<MST_EPI_RESIDUAL, float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, gamma, col_scale,
-                                                 scale_cols, nullptr, s);
-    if (cdt == MST_F32) return dispatch<float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
-    if (cdt == MST_BF16) return dispatch<bf16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
-    return dispatch<f16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, s);
+                                                 scale_cols, nullptr, nullptr, s);
+    if (cdt == MST_F8E4M3) return dispatch<uint8_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, c_amax, s);
+    if (cdt == MST_F32) return dispatch<float>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, c_amax, s);
+    if (cdt == MST_BF16) return dispatch<bf16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, c_amax, s);
+    return dispatch<f16_t>(A8, lda, W8, ldw, bias, a_amax, w_scale, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, out_amax, c_amax, s);
 }

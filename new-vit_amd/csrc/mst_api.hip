@@ -118,9 +118,14 @@ int mst_quantize_fp8(const void* x, int dtype, int64_t n, float* amax, void* out
 
 int mst_gemm_fp8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int c_dtype, int64_t ldc, int64_t M, int N, int K, int epilogue,
-                 const float* gamma, float col_scale, int scale_cols, mst_stream_t stream) {
+                 const float* gamma, float col_scale, int scale_cols, const float* c_amax, mst_stream_t stream) {
     return launch_gemm8(A8, lda, W8, ldw, bias, a_amax, w_scale, C, c_dtype, ldc, M, N, K, epilogue, gamma, col_scale,
-                        scale_cols, nullptr, (hipStream_t)stream);
+                        scale_cols, nullptr, c_dtype == MST_F8E4M3 ? c_amax : nullptr, (hipStream_t)stream);
+}
+
+int mst_layernorm_fp8(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out8,
+                      int64_t out_stride, int64_t rows, int cols, float eps, const float* amax, mst_stream_t stream) {
+    return launch_layernorm_f8(x, x_stride, gamma, beta, out8, out_stride, rows, cols, eps, amax, (hipStream_t)stream);
 }
 
 int mst_attention(const void* qkv, int dtype, int n_seq, int N, int heads, int head_dim, void* out,
@@ -220,6 +225,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     void* xn = (char*)ws + off_xn;
     void* big = (char*)ws + off_big;
     const bool fp8 = w->fp8_linear != 0;
+    const bool fp8_static = fp8 && w->fp8_amax != nullptr;   // calibrated scales: producers write e4m3, nothing is scanned
     void* a8 = fp8 ? (char*)ws + off_a8 : nullptr;
     float* amax = fp8 ? (float*)((char*)ws + off_amax) : nullptr;
     if (fp8) {
@@ -264,14 +270,18 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         for (int l = 0; l < w->depth && fused; ++l)
             fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
         if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
-        if (fp8 && hipMemsetAsync(amax, 0, (size_t)w->depth * 4 * sizeof(float), s) != hipSuccess) {
+        if (fp8 && !fp8_static && hipMemsetAsync(amax, 0, (size_t)w->depth * 4 * sizeof(float), s) != hipSuccess) {
             mst_set_error("vit_encode: hipMemsetAsync(amax) failed");
             return MST_ELAUNCH;
         }
         for (int l = 0; l < w->depth; ++l) {
             const mst_vit_layer* L = &w->layers[l];
             // x += ls1(proj(attn(qkv(norm1 x))))                       block.py:90-91,112
-            if (fp8) {
+            if (fp8_static) {
+                const float* am = w->fp8_amax + l * 4;
+                RUNK(MST_K_LAYERNORM, launch_layernorm_f8(x, E, L->ln1_w, L->ln1_b, a8, E, Mc, E, 1e-6f, am + 0, s));
+                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, nullptr, s));
+            } else if (fp8) {
                 // every linear layer: quantise its input with a fresh per-tensor scale (this chunk's max|x|), e4m3 GEMM.  The
                 // [M,E] inputs are scanned (53 us; a running maximum kept by the one-wave-per-row LayerNorm kernel cost 125 us:
                 // 350 k waves polling one address serialise in one L2 channel); the 4x larger hidden activation gets its maximum
@@ -279,7 +289,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 float* am = amax + l * 4;
                 RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
                 RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, 1, s));
-                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, s));
+                RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, nullptr, s));
             } else if (fused) {
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             } else {
@@ -293,15 +303,25 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, log2q, s));
             if (dt == MST_F32) RUNK(MST_K_ATTENTION, launch_attn32((const float*)big, c, N, heads, (float*)xn, s));
             else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
+            if (fp8_static) {
+                // the e4m3 hidden activation lives in `big` (bytes); fc1 reads a8 and writes big, fc2 reads big
+                float* am = const_cast<float*>(w->fp8_amax) + l * 4;   // launch_quant8 with scan = 0 only reads it
+                RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, 0, s));
+                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, nullptr, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm_f8(x, E, L->ln2_w, L->ln2_b, a8, E, Mc, E, 1e-6f, am + 2, s));
+                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, MST_F8E4M3, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, nullptr, am + 3, s));
+                RUNK(MST_K_GEMM_FC2, launch_gemm8(big, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, nullptr, s));
+                continue;
+            }
             if (fp8) {
                 float* am = amax + l * 4;
                 RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, 1, s));
-                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, s));
+                RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, nullptr, s));
                 RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln2_w, L->ln2_b, xn, dt, E, Mc, E, 1e-6f, s));
                 RUN(launch_quant8(xn, dt, Mc * E, am + 2, a8, 1, s));
-                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, s));
+                RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, nullptr, s));
                 RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, 0, s));
-                RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, s));
+                RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, nullptr, s));
                 continue;
             }
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
@@ -314,6 +334,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUNK(MST_K_GEMM_FC2, mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
             }
         }
+        if (fp8 && !fp8_static && w->fp8_amax_out) RUN(launch_amax_merge(w->fp8_amax_out, amax, w->depth * 4, s));
         // final norm, CLS rows only (vision_transformer.py:263-265,329)
         RUN(launch_layernorm(x, (int64_t)N * E, w->norm_w, w->norm_b, cls_out + (int64_t)s0 * E, MST_F32, E, c, E, 1e-6f, s));
     }

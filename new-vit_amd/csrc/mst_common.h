@@ -166,9 +166,13 @@ int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw
 // scan: 1 = *amax = max(*amax, max|x|) first (one extra pass over x); 0 = *amax already covers x (its producer kept it)
 int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s);
 // out_amax (nullable, 16-bit C, non-residual epilogues): *out_amax = max(*out_amax, max |C as stored|)
+// c_amax (cdt == MST_F8E4M3 only): calibrated scale of the e4m3 output
 int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
                  float w_scale, void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
-                 float col_scale, int scale_cols, float* out_amax, hipStream_t s);
+                 float col_scale, int scale_cols, float* out_amax, const float* c_amax, hipStream_t s);
+int launch_layernorm_f8(const float* x, int64_t xs, const float* g, const float* b, void* out8, int64_t os, int64_t rows,
+                        int cols, float eps, const float* amax, hipStream_t s);
+int launch_amax_merge(float* out, const float* in, int n, hipStream_t s);
 int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float* b1f, const float* b2, int64_t M, int E,
                  float eps, hipStream_t s);
 // log2q: q arrives pre-multiplied by log2(e) as well (the encoder folds it into the QKV epilogue's fp32 q scaling, so no

@@ -16,7 +16,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MST_HIP_LIB", _HERE / "libmst_hip.so"))
 
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, F8E4M3 = 0, 1, 2, 3
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL = 0, 1, 2, 3
 FUSION_TRANSFORMER, FUSION_LINEAR, FUSION_AVERAGE = 0, 1, 2
 
@@ -42,7 +42,8 @@ class VitWeights(C.Structure):
     _fields_ = [("embed_dim", _i), ("depth", _i), ("num_heads", _i), ("num_registers", _i),
                 ("compute_dtype", _i), ("grid_h", _i), ("grid_w", _i),
                 ("patch_w", _vp), ("patch_b", _vp), ("prefix", _vp), ("pos_patch", _vp),
-                ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp), ("fp8_linear", _i)]
+                ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp), ("fp8_linear", _i),
+                ("fp8_amax", _vp), ("fp8_amax_out", _vp)]
 
 
 class FusionWeights(C.Structure):
@@ -60,7 +61,8 @@ SIGNATURES = {
     "mst_layernorm": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i64, _i64, _i, _f, _vp]),
     "mst_gemm": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp]),
     "mst_quantize_fp8": (_i, [_vp, _i, _i64, _vp, _vp, _vp]),
-    "mst_gemm_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp]),
+    "mst_gemm_fp8": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _vp, _i, _i64, _i64, _i, _i, _i, _vp, _f, _i, _vp, _vp]),
+    "mst_layernorm_fp8": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i, _f, _vp, _vp]),
     "mst_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_cls_probs": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -182,15 +184,29 @@ def quantize_fp8(x: torch.Tensor, amax: Optional[torch.Tensor] = None) -> Tuple[
 
 def gemm_fp8(a8: torch.Tensor, a_amax: torch.Tensor, w8: torch.Tensor, w_scale: float, bias: Optional[torch.Tensor], *,
              epilogue: int = EPI_BIAS, out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
-             gamma: Optional[torch.Tensor] = None, col_scale: float = 1.0, scale_cols: int = 0) -> torch.Tensor:
+             gamma: Optional[torch.Tensor] = None, col_scale: float = 1.0, scale_cols: int = 0,
+             c_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """c_amax given: the output is e4m3 bytes (uint8) under that calibrated scale."""
     _dev(a8, "gemm_fp8")
     _dev(w8, "gemm_fp8")
     M, K = a8.shape
     N = w8.shape[0]
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
-    _check(load().mst_gemm_fp8(ptr(a8), K, ptr(w8), K, ptr(bias), ptr(a_amax), w_scale, ptr(out), dt_of(out), N, M, N, K,
-                               epilogue, ptr(gamma), col_scale, scale_cols, stream_of(a8)), "mst_gemm_fp8")
+        out = torch.empty((M, N), dtype=torch.uint8 if c_amax is not None else out_dtype, device=a8.device)
+    cdt = F8E4M3 if c_amax is not None else dt_of(out)
+    _check(load().mst_gemm_fp8(ptr(a8), K, ptr(w8), K, ptr(bias), ptr(a_amax), w_scale, ptr(out), cdt, N, M, N, K,
+                               epilogue, ptr(gamma), col_scale, scale_cols, ptr(c_amax), stream_of(a8)), "mst_gemm_fp8")
+    return out
+
+
+def layernorm_fp8(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                  amax: torch.Tensor) -> torch.Tensor:
+    """mst_layernorm_fp8: LayerNorm over the last dim of fp32 x [rows, cols] -> e4m3 bytes under the calibrated scale."""
+    _dev(x, "layernorm_fp8")
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    _check(load().mst_layernorm_fp8(ptr(x), cols, ptr(gamma), ptr(beta), ptr(out), cols, rows, cols, eps, ptr(amax),
+                                    stream_of(x)), "mst_layernorm_fp8")
     return out
 
 

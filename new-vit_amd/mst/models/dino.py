@@ -199,6 +199,8 @@ class DinoV2ClassifierSlice(BasicClassifier):
             raise ValueError(f"compute_dtype must be one of {sorted(hip.DT_NAMES)}")
         super().__init__(in_ch, out_ch, spatial_dims=spatial_dims, optimizer_kwargs=optimizer_kwargs, **kwargs)
         self.compute_dtype_name = compute_dtype
+        self._fp8_amax = self._fp8_calib = None      # calibrate_fp8(): static activation scales of the fp8 mode
+        self._fp8_collect = False
         self.chunk_slices = chunk_slices
         self.full_attention_maps = full_attention_maps
         self.save_attn = save_attn
@@ -278,8 +280,33 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self._sharding = None
 
     # ---- weight preparation -------------------------------------------------------------------------
+    # ---- fp8 mode: calibrated (static) activation scales ------------------------------------------------
+    def calibrate_fp8(self, source, margin: float = 1.0, **kwargs):
+        """compute_dtype='fp8' only.  Runs ``forward(source, **kwargs)`` with dynamic scales, records max|x| of the inputs
+        of the four linear layers of every block ([depth, 4], kept over successive calls until ``reset_fp8_calibration``),
+        and switches later forwards to those scales times ``margin``: LayerNorm and the GELU epilogue then write e4m3 directly
+        and nothing is scanned.  Values beyond the calibrated range saturate.  Returns the scale table (a copy)."""
+        if self.compute_dtype_name not in hip.FP8_NAMES:
+            raise RuntimeError("calibrate_fp8 needs compute_dtype='fp8'")
+        if self._fp8_calib is None:
+            self._fp8_calib = torch.zeros(self.encoder.depth * 4, dtype=torch.float32, device=self.device)
+        self._fp8_amax, self._fp8_collect = None, True
+        try:
+            with torch.no_grad():
+                self(source, **kwargs)
+        finally:
+            self._fp8_collect = False
+        self._fp8_amax = (self._fp8_calib * float(margin)).contiguous()
+        return self._fp8_amax.view(self.encoder.depth, 4).clone()
+
+    def reset_fp8_calibration(self):
+        """Back to dynamic per-call scales."""
+        self._fp8_amax = self._fp8_calib = None
+        self._fp8_collect = False
+
     def _signature(self):
         return (self.compute_dtype_name, str(self.device),
+                None if self._fp8_amax is None else (self._fp8_amax.data_ptr(), self._fp8_amax._version), self._fp8_collect,
                 tuple((p.data_ptr(), p._version) for p in self.parameters()))
 
     def _prepare(self):
@@ -355,6 +382,10 @@ class DinoV2ClassifierSlice(BasicClassifier):
         vit.embed_dim, vit.depth, vit.num_heads, vit.num_registers = E, enc.depth, enc.num_heads, R
         vit.compute_dtype = cdt
         vit.fp8_linear = 1 if fp8 else 0
+        if fp8 and self._fp8_amax is not None:
+            vit.fp8_amax = hip.ptr(self._fp8_amax)
+        elif fp8 and self._fp8_collect:
+            vit.fp8_amax_out = hip.ptr(self._fp8_calib)
         vit.patch_w, vit.patch_b = hip.ptr(wp), hip.ptr(f32(enc.patch_embed.proj.bias))
         vit.prefix = hip.ptr(prefix)
         vit.layers = layers

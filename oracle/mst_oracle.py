@@ -109,10 +109,11 @@ def prepare_tokens(sd: SD, slices: Tensor) -> Tensor:
 F8_MAX = 448.0   # largest finite OCP e4m3
 
 
-def fp8_e4m3(x: Tensor) -> Tuple[Tensor, float]:
+def fp8_e4m3(x: Tensor, amax: Optional[float] = None) -> Tuple[Tensor, float]:
     """Per-tensor e4m3 quantisation: (values representable in e4m3 as fp32, scale = max|x|/448), x ~ scale * values.
-    The multiplier 448/max|x| is formed and applied in fp32, rounding to e4m3 is to nearest-even."""
-    amax = x.detach().abs().max().to(torch.float32)
+    The multiplier 448/max|x| is formed and applied in fp32, rounding to e4m3 is to nearest-even.  `amax` given: a calibrated
+    (static) scale replaces max|x|; larger values saturate at +-448 quanta."""
+    amax = x.detach().abs().max().to(torch.float32) if amax is None else torch.tensor(float(amax), dtype=torch.float32)
     if float(amax) == 0.0:
         return torch.zeros_like(x, dtype=torch.float32), 1.0
     inv = torch.tensor(F8_MAX, dtype=torch.float32) / amax
@@ -120,57 +121,63 @@ def fp8_e4m3(x: Tensor) -> Tuple[Tensor, float]:
     return q, float(amax) / F8_MAX
 
 
-def fp8_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+def fp8_linear(x: Tensor, w: Tensor, b: Optional[Tensor], amax: Optional[float] = None) -> Tensor:
     """F.linear with OCP-e4m3 operands, per-tensor absmax scales and wide accumulation -- the arithmetic BASELINE.json
     configs[4] / SURVEY.md 8d row c5 name ("fp8-e4m3 operands, per-tensor scales from absmax").  PARITY UNPINNED: the
     reference has no fp8 code; this restates F.linear (attention.py:58,67; mlp.py:35,38) with both operands rounded."""
-    xq, sx = fp8_e4m3(x)
+    xq, sx = fp8_e4m3(x, amax)
     wq, sw = fp8_e4m3(w)
     y = (xq.double() @ wq.double().t()) * (sx * sw)
     return (y + (b.double() if b is not None else 0.0)).to(x.dtype)
 
 
-_LINEAR = {"exact": F.linear, "fp8": fp8_linear}
+def _linear_fn(linear: str, amax, j: int):
+    """F.linear, or fp8_linear with the j-th calibrated activation scale of the block (None = dynamic)."""
+    if linear == "exact":
+        return F.linear
+    assert linear == "fp8", linear
+    a = None if amax is None else float(amax[j])
+    return lambda x, w, b: fp8_linear(x, w, b, a)
 
 
-def vit_attention(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact") -> Tuple[Tensor, Tensor]:
+def vit_attention(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact", amax=None) -> Tuple[Tensor, Tensor]:
     """attention.py:56-69 (== dino.py:226-243 with the softmax kept).  Returns (out, probs)."""
     n, N, C = x.shape
     d = C // heads
-    lin = _LINEAR[linear]
-    qkv = lin(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
+    qkv = _linear_fn(linear, amax, 0)(x, sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"])
     qkv = qkv.reshape(n, N, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
     probs = (q @ k.transpose(-2, -1)).softmax(dim=-1)
     out = (probs @ v).transpose(1, 2).reshape(n, N, C)
-    return lin(out, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), probs
+    return _linear_fn(linear, amax, 1)(out, sd[p + ".attn.proj.weight"], sd[p + ".attn.proj.bias"]), probs
 
 
-def vit_block(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact") -> Tuple[Tensor, Tensor]:
-    """block.py:89-114 eval branch: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)); LN eps 1e-6."""
-    lin = _LINEAR[linear]
-    a, probs = vit_attention(layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6), sd, p, heads, linear)
+def vit_block(x: Tensor, sd: SD, p: str, heads: int, linear: str = "exact", amax=None) -> Tuple[Tensor, Tensor]:
+    """block.py:89-114 eval branch: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)); LN eps 1e-6.
+    amax: 4 calibrated activation scales (inputs of qkv, proj, fc1, fc2) for linear='fp8', or None (dynamic)."""
+    a, probs = vit_attention(layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6), sd, p, heads, linear, amax)
     if (p + ".ls1.gamma") in sd:  # layer_scale.py:26-27
         a = a * sd[p + ".ls1.gamma"]
     x = x + a
     h = layer_norm(x, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6)
-    h = lin(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])           # mlp.py:34-40
-    h = lin(gelu_erf(h), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
+    h = _linear_fn(linear, amax, 2)(h, sd[p + ".mlp.fc1.weight"], sd[p + ".mlp.fc1.bias"])           # mlp.py:34-40
+    h = _linear_fn(linear, amax, 3)(gelu_erf(h), sd[p + ".mlp.fc2.weight"], sd[p + ".mlp.fc2.bias"])
     if (p + ".ls2.gamma") in sd:
         h = h * sd[p + ".ls2.gamma"]
     return x + h, probs
 
 
-def vit_encode(sd: SD, slices: Tensor, model_size: str = "s", keep: str = "none", linear: str = "exact"):
+def vit_encode(sd: SD, slices: Tensor, model_size: str = "s", keep: str = "none", linear: str = "exact", act_amax=None):
     """DinoVisionTransformer.forward (vision_transformer.py:254-270,324-329) -> normalised CLS [n,E].
 
     keep: 'none' | 'cls' (CLS row of every block's softmax, [n,h,1,N] each) | 'full' ([n,h,N,N]).
-    linear: 'exact' (the reference) | 'fp8' (the blocks' four linear layers through fp8_linear; everything else unchanged)."""
+    linear: 'exact' (the reference) | 'fp8' (the blocks' four linear layers through fp8_linear; everything else unchanged).
+    act_amax: [depth][4] calibrated activation scales for 'fp8' (None = per-call absmax)."""
     cfg = VIT_CFG[model_size]
     x = prepare_tokens(sd, slices)
     maps: List[Tensor] = []
     for i in range(cfg["depth"]):
-        x, probs = vit_block(x, sd, _block_prefix(sd, i), cfg["num_heads"], linear)
+        x, probs = vit_block(x, sd, _block_prefix(sd, i), cfg["num_heads"], linear, None if act_amax is None else act_amax[i])
         if keep == "cls":
             maps.append(probs[:, :, :1].clone())
         elif keep == "full":

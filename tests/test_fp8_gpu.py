@@ -266,3 +266,96 @@ def test_fp8_hub_layout_layerscale_registers():
     model.encoder = _ViT(384, 12, 6, img_size=518, num_register_tokens=4, layerscale=1.0, chunked=False)
     model.load_state_dict(sd, strict=True)
     _noise_check(model.cuda().eval(), sd, synth.synth_volume((1, 1, 3, 70, 98), 21), "s", regs=4)
+
+
+# ---- calibrated (static) activation scales: producers write e4m3 directly, nothing is scanned ------------------------------
+def _mismatch(got8, ref8):
+    """(fraction of differing bytes, max |difference| in e4m3 grid steps of the reference value)."""
+    g, r = got8.cpu().view(torch.float8_e4m3fn).float(), ref8.cpu().view(torch.float8_e4m3fn).float()
+    frac = float((got8.cpu() != ref8.cpu()).float().mean())
+    step = torch.exp2(torch.floor(torch.log2(r.abs().clamp_min(2.0 ** -6))) - 3)   # ulp of the reference's binade (3 mantissa bits)
+    return frac, float(((g - r).abs() / step).max())
+
+
+def test_layernorm_fp8_static_scale(hip):
+    x = rnd((777, 384), 30) * 2 + 0.3
+    g, b = rnd((384,), 31) * 0.2 + 1, rnd((384,), 32) * 0.1
+    y = torch.nn.functional.layer_norm(x.double(), (384,), g.double(), b.double(), 1e-6)
+    for amax in (float(y.abs().max()), 2.5):                            # exact range; a tighter calibrated range saturates
+        a = torch.tensor([amax], device="cuda")
+        got = hip.layernorm_fp8(x.cuda(), g.cuda(), b.cuda(), 1e-6, a)
+        ref = (y.float() * (torch.tensor(F8_MAX) / amax)).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+        frac, ulps = _mismatch(got, ref)
+        # fp32 LayerNorm on the GPU vs fp64 here: a value within 1e-6 of a rounding boundary may land on the other side
+        assert frac < 2e-3 and ulps <= 1.0, (amax, frac, ulps)
+
+
+def test_gemm_fp8_e4m3_output(hip):
+    M, N, K = 1000, 1536, 384
+    a8, sa, w8, sw = _operands(M, N, K, 40)
+    bias = rnd((N,), 42) * 0.1
+    amax = torch.tensor([sa * F8_MAX], device="cuda")
+    base = (deq(a8) @ deq(w8).t()) * (sa * sw) + bias.double()
+    gelu = 0.5 * base * (1 + torch.erf(base / math.sqrt(2)))
+    c_amax = float(gelu.abs().max()) * 0.8                               # calibrated a little tight: the top saturates
+    ca = torch.tensor([c_amax], device="cuda")
+    got = hip.gemm_fp8(a8.cuda(), amax, w8.cuda(), sw, bias.cuda(), epilogue=hip.EPI_BIAS_GELU, c_amax=ca)
+    assert got.dtype == torch.uint8 and got.shape == (M, N)
+    ref = (gelu.float() * (torch.tensor(F8_MAX) / c_amax)).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    frac, ulps = _mismatch(got, ref)
+    # fp32 accumulation + the fast GELU (|err| 5e-7) against fp64: boundary cases only
+    assert frac < 5e-3 and ulps <= 1.0, (frac, ulps)
+    with pytest.raises(RuntimeError, match="e4m3 C needs"):
+        hip.gemm_fp8(a8.cuda(), amax, w8.cuda(), sw, None, epilogue=hip.EPI_RESIDUAL, c_amax=ca,
+                     out=torch.zeros(M, N, dtype=torch.uint8, device="cuda"))
+
+
+def test_fp8_calibrated_scales_against_oracle():
+    """calibrate_fp8 on the sample itself: the table equals the dynamic run's scales, the static forward stays within the
+    quantisation noise of the oracle given the same table, later calls are deterministic, reset returns to dynamic."""
+    from oracle import mst_oracle as O
+    model, sd = _model("fp8", seed=0)
+    src = synth.synth_volume((1, 1, 16, 224, 224), 0)
+    flat = src.reshape(16, 224, 224)
+    with torch.no_grad():
+        dyn = model.encode_slices(flat.cuda())[0].cpu()
+        table = model.calibrate_fp8(src)
+        assert table.shape == (12, 4) and bool((table > 0).all())
+        sta = model.encode_slices(flat.cuda())[0].cpu()
+        sta2 = model.encode_slices(flat.cuda())[0].cpu()
+        ref8, _ = O.vit_encode(sd, flat, "s", linear="fp8", act_amax=table.cpu().tolist())
+        ref, _ = O.vit_encode(sd, flat, "s")
+        model.reset_fp8_calibration()
+        dyn2 = model.encode_slices(flat.cuda())[0].cpu()
+    assert torch.equal(sta, sta2) and torch.equal(dyn, dyn2)
+    e8, ex, eq, ed = rel_l2(sta, ref8), rel_l2(sta, ref), rel_l2(ref8, ref), rel_l2(sta, dyn)
+    print(f"fp8 static scales: emb rel-L2 HIP-fp8oracle {e8:.3e}, HIP-exact {ex:.3e}, fp8oracle-exact {eq:.3e}, static-dynamic {ed:.3e}")
+    assert ex < 1.5 * eq and e8 < 1.5 * eq and ed < 1.5 * eq
+
+
+def test_fp8_calibrated_single_block_is_tighter_than_dynamic():
+    """With static scales LayerNorm and GELU outputs are quantised from fp32 (no bf16 carrier in between), so one block sits
+    closer to the oracle than in the dynamic mode (4.1e-2 there)."""
+    from oracle import mst_oracle as O
+    from mst.models import DinoV2ClassifierSlice
+    from mst.models.dino import _ViT
+    sd = {k: v for k, v in synth.synth_state_dict("s", 4).items()
+          if not (k.startswith("encoder.blocks.0.") and k.split(".")[3] != "0")}
+    model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8")
+    model.encoder = _ViT(384, 1, 6)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    O.VIT_CFG["s_depth1"] = dict(embed_dim=384, depth=1, num_heads=6)
+    src = synth.synth_volume((1, 1, 6, 112, 112), 8)
+    flat = src.reshape(6, 112, 112)
+    try:
+        with torch.no_grad():
+            table = model.calibrate_fp8(src)
+            emb = model.encode_slices(flat.cuda())[0].cpu()
+            ref8, _ = O.vit_encode(sd, flat, "s_depth1", linear="fp8", act_amax=table.cpu().tolist())
+            ref, _ = O.vit_encode(sd, flat, "s_depth1")
+    finally:
+        del O.VIT_CFG["s_depth1"]
+    e8, q = rel_l2(emb, ref8), rel_l2(ref8, ref)
+    print(f"fp8 static one block: emb rel-L2 vs fp8 oracle {e8:.3e}; block quantisation noise {q:.3e}")
+    assert e8 < 0.75 * q
