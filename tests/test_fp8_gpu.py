@@ -305,8 +305,9 @@ def test_gemm_fp8_e4m3_output(hip):
     ref = (gelu.float() * (torch.tensor(F8_MAX) / c_amax)).clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
     # the fp8 MFMA's accumulation error is absolute (GEMM_TOL of max|C|, see above): small outputs sit on a finer e4m3 grid than
     # that error, so it is allowed for in quanta before counting grid steps
-    frac, ulps = _mismatch(got, ref, abs_quanta=GEMM_TOL * float(base.abs().max()) * F8_MAX / c_amax)
-    assert frac < 5e-3 and ulps <= 1.0, (frac, ulps)
+    # ... and so is the error of the sigmoid-form GELU the 16-bit / e4m3 epilogues use (2.7e-4, mst_common.h)
+    frac, ulps = _mismatch(got, ref, abs_quanta=(GEMM_TOL * float(base.abs().max()) + 3e-4) * F8_MAX / c_amax)
+    assert frac < 2e-2 and ulps <= 1.0, (frac, ulps)
     with pytest.raises(RuntimeError, match="e4m3 C needs"):
         hip.gemm_fp8(a8.cuda(), amax, w8.cuda(), sw, None, epilogue=hip.EPI_RESIDUAL, c_amax=ca,
                      out=torch.zeros(M, N, dtype=torch.uint8, device="cuda"))
