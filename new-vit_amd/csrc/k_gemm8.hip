@@ -304,7 +304,8 @@ int launch_amax_merge(float* out, const float* in, int n, hipStream_t s) {
     return mst_check_launch("amax_merge");
 }
 
-int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s) {
+// scan: *amax = max(*amax, max|x|) first (amax_rw != nullptr), then quantise under `amax`
+static int quant8_impl(const void* x, int dt, int64_t n, float* amax_rw, const float* amax, void* out8, hipStream_t s) {
     MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "quantize_fp8: input dtype %d must be bf16 or fp16", dt);
     MST_CHECK_ARG(n >= 0 && n % 8 == 0, "quantize_fp8: n=%lld must be a multiple of 8", (long long)n);
     if (n == 0) return MST_OK;
@@ -312,13 +313,21 @@ int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int
     const int64_t want = (n8 + 255) / 256;
     const int grid = (int)(want < 4096 ? want : 4096);
     if (dt == MST_BF16) {
-        if (scan) absmax_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, (unsigned int*)amax);
+        if (amax_rw) absmax_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, (unsigned int*)amax_rw);
         quant8_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, n8, amax, (uint8_t*)out8);
     } else {
-        if (scan) absmax_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, (unsigned int*)amax);
+        if (amax_rw) absmax_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, (unsigned int*)amax_rw);
         quant8_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, n8, amax, (uint8_t*)out8);
     }
     return mst_check_launch("quantize_fp8");
+}
+
+int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s) {
+    return quant8_impl(x, dt, n, scan ? amax : nullptr, amax, out8, s);
+}
+
+int launch_quant8_static(const void* x, int dt, int64_t n, const float* amax, void* out8, hipStream_t s) {
+    return quant8_impl(x, dt, n, nullptr, amax, out8, s);
 }
 
 int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,

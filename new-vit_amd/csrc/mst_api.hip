@@ -305,8 +305,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
             if (fp8_static) {
                 // the e4m3 hidden activation lives in `big` (bytes); fc1 reads a8 and writes big, fc2 reads big
-                float* am = const_cast<float*>(w->fp8_amax) + l * 4;   // launch_quant8 with scan = 0 only reads it
-                RUN(launch_quant8(xn, dt, Mc * E, am + 1, a8, 0, s));
+                const float* am = w->fp8_amax + l * 4;
+                RUN(launch_quant8_static(xn, dt, Mc * E, am + 1, a8, s));
                 RUNK(MST_K_GEMM_PROJ, launch_gemm8(a8, E, L->proj_w8, E, L->proj_b, am + 1, L->w8_scale[1], x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, nullptr, nullptr, s));
                 RUNK(MST_K_LAYERNORM, launch_layernorm_f8(x, E, L->ln2_w, L->ln2_b, a8, E, Mc, E, 1e-6f, am + 2, s));
                 RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, MST_F8E4M3, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, nullptr, am + 3, s));

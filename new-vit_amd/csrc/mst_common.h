@@ -165,6 +165,8 @@ int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw
                         int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols, hipStream_t s);
 // scan: 1 = *amax = max(*amax, max|x|) first (one extra pass over x); 0 = *amax already covers x (its producer kept it)
 int launch_quant8(const void* x, int dt, int64_t n, float* amax, void* out8, int scan, hipStream_t s);
+// quantise under a calibrated scale the caller owns (read-only)
+int launch_quant8_static(const void* x, int dt, int64_t n, const float* amax, void* out8, hipStream_t s);
 // out_amax (nullable, 16-bit C, non-residual epilogues): *out_amax = max(*out_amax, max |C as stored|)
 // c_amax (cdt == MST_F8E4M3 only): calibrated scale of the e4m3 output
 int launch_gemm8(const void* A8, int64_t lda, const void* W8, int64_t ldw, const float* bias, const float* a_amax,
