@@ -185,3 +185,33 @@ def test_fp8_weight_quantisation_host_side():
     z8, zs = hip.quantize_weight_fp8(torch.zeros(8, 16))
     assert int(z8.max()) == 0 and zs == 1.0
     assert "fp8" in hip.DT_NAMES and hip.DT_NAMES["fp8"] == hip.BF16 and "fp8" in hip.FP8_NAMES
+
+
+def test_oracle_fp8_calibrated_table_reproduces_the_dynamic_run():
+    """The oracle's two fp8 modes agree when the calibrated table holds exactly the per-call maxima: pins the order of the
+    table's columns (inputs of qkv, proj, fc1, fc2) and its [depth][4] indexing."""
+    import torch
+    from mst import synth
+    from oracle import mst_oracle as O
+    sd = synth.synth_state_dict("s", 1)
+    x = synth.synth_volume((1, 1, 2, 28, 42), 3).reshape(2, 28, 42)
+    seen = []
+    real = O.fp8_e4m3
+
+    def spy(t, amax=None):
+        seen.append(float(t.detach().abs().max()))
+        return real(t, amax)
+
+    O.fp8_e4m3 = spy
+    try:
+        with torch.no_grad():
+            dyn, _ = O.vit_encode(sd, x, "s", linear="fp8")
+    finally:
+        O.fp8_e4m3 = real
+    assert len(seen) == 12 * 4 * 2                          # activation then weight, four linear layers, twelve blocks
+    table = torch.tensor(seen[0::2]).reshape(12, 4).tolist()
+    with torch.no_grad():
+        sta, _ = O.vit_encode(sd, x, "s", linear="fp8", act_amax=table)
+        half, _ = O.vit_encode(sd, x, "s", linear="fp8", act_amax=(torch.tensor(table) * 0.5).tolist())
+    assert torch.equal(sta, dyn)
+    assert not torch.equal(half, dyn)                       # a too-tight table saturates the largest values
