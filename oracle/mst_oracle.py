@@ -10,6 +10,10 @@ Parity status: PINNED.  ``tools/gen_golden.py`` ran the reference's own modules 
 fixtures in ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function below against
 them (the reference's own tests hold no numerical vectors: SURVEY.md section 4).
 
+Exception -- ``fp8_e4m3`` / ``fp8_linear`` (``linear="fp8"``): PARITY UNPINNED.  The reference has no fp8 code; these restate the
+arithmetic BASELINE.json configs[4] names (OCP e4m3 operands, per-tensor absmax scales) on top of the pinned fp32 functions and
+are only anchored by torch's own ``float8_e4m3fn`` cast.
+
 Each function cites the reference lines it restates (paths relative to /root/reference).
 """
 from __future__ import annotations
