@@ -4,6 +4,10 @@ scripts/main_predict.py:27-28 import from here and from the sub-modules).
 ``DinoV2ClassifierSlice`` is the MI355X hot path; ``DinoV3ClassifierSlice``, ``ResNet`` and ``ResNetSliceTrans`` exist so that
 the scripts' imports and ``isinstance`` dispatch keep working (they raise on construction: out of scope).
 """
+from pkgutil import extend_path
+
+__path__ = extend_path(__path__, __name__)   # mst.models.extern etc. fall through to a reference checkout (mst/__init__.py)
+
 from .base_model import BasicClassifier, BasicModel
 from .dino import DinoV2ClassifierSlice, DinoV3ClassifierSlice
 from .resnet import ResNet, ResNetSliceTrans
