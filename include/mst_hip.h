@@ -139,6 +139,21 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
 int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2f,
                   int64_t M, int E, float eps, mst_stream_t stream);
 
+/* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only).  A caller-owned object:
+ * while mst_vit_weights.profiler points at one, every launch of that call is bracketed by hipEventRecord on the call's own
+ * stream; mst_profiler_collect waits for the recorded events, returns the accumulated milliseconds and launch counts per
+ * kernel kind since the last collect, and resets.  No process-global state: calls without a profiler record nothing. */
+typedef struct mst_profiler mst_profiler;
+enum mst_kernel_kind {
+    MST_K_PATCH_EMBED = 0, MST_K_LAYERNORM = 1, MST_K_GEMM_QKV = 2, MST_K_ATTENTION = 3,
+    MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_MLP_FUSED = 8,
+    MST_K_COUNT = 9
+};
+mst_profiler* mst_profiler_create(void);
+void mst_profiler_destroy(mst_profiler* p);
+int mst_profiler_collect(mst_profiler* p, double* ms_total, int64_t* launches); /* arrays of MST_K_COUNT */
+const char* mst_kernel_kind_name(int kind);
+
 /* Whole per-slice encoder ------------------------------------------------------------------ */
 typedef struct mst_vit_layer {
     const float* ln1_w; const float* ln1_b;       /* block.py:63  */
@@ -179,6 +194,7 @@ typedef struct mst_vit_weights {
                                    * and the GELU epilogue then write e4m3 directly and nothing is scanned */
     float* fp8_amax_out;          /* dynamic mode, nullable: device fp32 [depth][4], out[i] = max(out[i], this call's scales):
                                    * zero it, run representative inputs, and pass it back as fp8_amax (calibration) */
+    mst_profiler* profiler;       /* nullable: time this call's launches (see mst_profiler_create) */
 } mst_vit_weights;
 
 /* DinoVisionTransformer.forward on n_slices gray slices (vision_transformer.py:254-270,324-329;
@@ -215,6 +231,8 @@ typedef struct mst_fusion_weights {
     const float* rope_freqs;                              /* [head_dim/2] or NULL (RoPE) */
     const float* head_w; const float* head_b;             /* [out_ch, emb*] (dino.py:103) */
     const float* liere_rot;                               /* [head_dim, head_dim] from mst_liere_rotation, or NULL (LieRE) */
+    int head_in;     /* columns of head_w: emb, or 32*emb for 'linear' fusion (dino.py:245).  The feature width of the call
+                      * (emb*D for 'linear') must equal it, as nn.Linear would insist; 0 = unchecked */
 } mst_fusion_weights;
 
 /* dino.py:134-166 after the encoder: bottleneck, slice position embedding, CLS concat,
@@ -259,19 +277,6 @@ int mst_liere_rotation(const float* vars, int n_blocks, int block, int axes_leng
  * when n_layers <= 2.  Neither may alias a map.  n_layers == 1 copies the map. */
 int mst_attention_rollout(const float* const* maps, int n_layers, int64_t batch, int N, float* out,
                           float* tmp, mst_stream_t stream);
-
-/* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only; off by
- * default).  When enabled, every launch is bracketed by hipEventRecord on the call's own stream;
- * mst_profile_collect waits for the recorded events, returns the accumulated milliseconds and
- * launch counts per kernel kind since the last collect, and resets.  Process-global state. */
-enum mst_kernel_kind {
-    MST_K_PATCH_EMBED = 0, MST_K_LAYERNORM = 1, MST_K_GEMM_QKV = 2, MST_K_ATTENTION = 3,
-    MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_MLP_FUSED = 8,
-    MST_K_COUNT = 9
-};
-int mst_profile_enable(int on);
-int mst_profile_collect(double* ms_total, int64_t* launches); /* arrays of MST_K_COUNT */
-const char* mst_kernel_kind_name(int kind);
 
 #ifdef __cplusplus
 }

@@ -544,6 +544,16 @@ int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* ou
 
 int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q, hipStream_t s) {
     MST_CHECK_ARG(N > 0 && N <= 12000 && hd > 0 && hd <= 256, "cls_probs: N=%d hd=%d unsupported", N, hd);
+    if (n_seq > 65535) {   // gridDim.y limit: walk the sequences in pieces
+        const size_t esz = dt == MST_F32 ? 4 : 2;
+        for (int s0 = 0; s0 < n_seq; s0 += 65535) {
+            const int c = (n_seq - s0 < 65535) ? n_seq - s0 : 65535;
+            int rc = launch_cls_probs((const char*)qkv + (size_t)s0 * N * 3 * heads * hd * esz, dt, c, N, heads, hd,
+                                      probs + (size_t)s0 * heads * N, log2q, s);
+            if (rc) return rc;
+        }
+        return MST_OK;
+    }
     const dim3 grid(heads, n_seq), block(256);
     const size_t sh = (size_t)(hd + N + 8) * sizeof(float);
     if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd, log2q);
@@ -563,6 +573,16 @@ int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int 
         return mst_check_launch("probs_full16");
     }
     MST_CHECK_ARG(N > 0 && N <= 3800 && hd > 0 && hd <= 256, "probs_full: N=%d hd=%d unsupported", N, hd);
+    if (n_seq > 65535) {   // gridDim.z limit: walk the sequences in pieces
+        const size_t esz = dt == MST_F32 ? 4 : 2;
+        for (int s0 = 0; s0 < n_seq; s0 += 65535) {
+            const int c = (n_seq - s0 < 65535) ? n_seq - s0 : 65535;
+            int rc = launch_probs_full((const char*)qkv + (size_t)s0 * N * 3 * heads * hd * esz, dt, c, N, heads, hd,
+                                       probs + (size_t)s0 * heads * N * N, log2q, s);
+            if (rc) return rc;
+        }
+        return MST_OK;
+    }
     const dim3 grid((N + 3) / 4, heads, n_seq), block(256);
     const size_t sh = (size_t)4 * (hd + N) * sizeof(float);
     if (dt == MST_BF16) probs_full_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd, log2q);

@@ -316,8 +316,17 @@ int launch_readout(const float* cls_probs, const float* slice_probs, int B, int 
         if (rc) return rc;
     }
     if (cls_probs && (plane || maps)) {
-        plane_readout_kernel<<<dim3(heads, B * D), dim3(256), 0, s>>>(cls_probs, heads, N, 1 + R, maps ? slice_attn : nullptr, plane, maps);
-        return mst_check_launch("plane_readout");
+        // gridDim.y is limited to 65535: walk the slices in pieces (B*D can exceed it for small slices)
+        const int64_t n = (int64_t)B * D, Np = N - 1 - R;
+        for (int64_t n0 = 0; n0 < n; n0 += 65535) {
+            const int c = (int)((n - n0 < 65535) ? n - n0 : 65535);
+            plane_readout_kernel<<<dim3(heads, c), dim3(256), 0, s>>>(cls_probs + n0 * heads * N, heads, N, 1 + R,
+                                                                      maps ? slice_attn + n0 : nullptr,
+                                                                      plane ? plane + n0 * heads * Np : nullptr,
+                                                                      maps ? maps + n0 * heads * Np : nullptr);
+            int rc = mst_check_launch("plane_readout");
+            if (rc) return rc;
+        }
     }
     return MST_OK;
 }

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "mst_common.h"
@@ -54,32 +55,34 @@ int mst_persistent_grid(void) {
     return cus[dev];
 }
 
-// ---- optional per-kernel event timing (bench only) -------------------------------------------------
+// ---- optional per-kernel event timing (bench only): state lives in a caller-owned mst_profiler -------------
+struct mst_profiler {
+    struct Rec { hipEvent_t a, b; int kind; };
+    std::mutex mu;
+    std::vector<Rec> used, idle;
+};
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; };
-std::mutex g_prof_mu;
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof_used, g_prof_free;
 const char* const kKindNames[MST_K_COUNT] = {"patch_embed", "layernorm", "gemm_qkv", "attention",
                                              "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs", "mlp_fused"};
 struct ProfScope {
-    ProfRec r{};
-    bool on = false;
+    mst_profiler* p;
+    mst_profiler::Rec r{};
     hipStream_t s;
-    ProfScope(int kind, hipStream_t st) : s(st) {
-        if (!g_prof_on) return;
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
-        else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+    ProfScope(mst_profiler* prof, int kind, hipStream_t st) : p(prof), s(st) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (!p->idle.empty()) { r = p->idle.back(); p->idle.pop_back(); }
+            else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+        }
         r.kind = kind;
-        on = true;
         (void)hipEventRecord(r.a, s);
     }
     ~ProfScope() {
-        if (!on) return;
+        if (!p) return;
         (void)hipEventRecord(r.b, s);
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        g_prof_used.push_back(r);
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->used.push_back(r);
     }
 };
 }  // namespace
@@ -204,6 +207,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                    void* ws, size_t ws_bytes, mst_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     MST_CHECK_ARG(w && vol && cls_out && ws, "vit_encode: null pointer");
+    mst_profiler* const prof = w->profiler;
     MST_CHECK_ARG(w->layers && w->depth > 0, "vit_encode: no layers");
     MST_CHECK_ARG(H > 0 && W > 0 && H % 14 == 0 && W % 14 == 0, "vit_encode: H=%d W=%d must be multiples of 14", H, W);
     MST_CHECK_ARG(H / 14 == w->grid_h && W / 14 == w->grid_w, "vit_encode: pos_patch prepared for grid %dx%d, input is %dx%d",
@@ -250,7 +254,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     do {                             \
         int rc_;                     \
         {                            \
-            ProfScope ps_(kind, s);  \
+            ProfScope ps_(prof, kind, s); \
             rc_ = (call);            \
         }                            \
         if (rc_) return rc_;         \
@@ -430,6 +434,8 @@ int mst_slice_fusion(const mst_fusion_weights* w, const float* emb, int B, int D
     if (logits) {  // dino.py:166
         MST_CHECK_ARG(w->head_w && w->out_ch > 0, "slice_fusion: logits requested without a head");
         MST_CHECK_ARG(F % 16 == 0, "slice_fusion: feature width %d must be a multiple of 16", F);
+        MST_CHECK_ARG(w->head_in <= 0 || F == w->head_in, "slice_fusion: mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)",
+                      B, F, w->head_in, w->out_ch);
         RUN(launch_gemm32(feat, F, w->head_w, F, w->head_b, logits, w->out_ch, B, w->out_ch, F, MST_EPI_BIAS, nullptr, 1.f, 0, s));
     }
     return MST_OK;
@@ -490,27 +496,30 @@ int mst_attention_rollout(const float* const* maps, int n_layers, int64_t batch,
     return MST_OK;
 }
 
-int mst_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
-    return MST_OK;
+mst_profiler* mst_profiler_create(void) { return new (std::nothrow) mst_profiler(); }
+
+void mst_profiler_destroy(mst_profiler* p) {
+    if (!p) return;
+    for (auto* v : {&p->used, &p->idle})
+        for (const auto& r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    delete p;
 }
 
-int mst_profile_collect(double* ms_total, int64_t* launches) {
-    MST_CHECK_ARG(ms_total && launches, "profile_collect: null pointer");
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+int mst_profiler_collect(mst_profiler* p, double* ms_total, int64_t* launches) {
+    MST_CHECK_ARG(p && ms_total && launches, "profiler_collect: null pointer");
+    std::lock_guard<std::mutex> lk(p->mu);
     for (int k = 0; k < MST_K_COUNT; ++k) { ms_total[k] = 0.0; launches[k] = 0; }
-    for (const ProfRec& r : g_prof_used) {
+    for (const auto& r : p->used) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
-            mst_set_error("profile_collect: event query failed");
+            mst_set_error("profiler_collect: event query failed");
             return MST_ELAUNCH;
         }
         ms_total[r.kind] += ms;
         launches[r.kind] += 1;
-        g_prof_free.push_back(r);
+        p->idle.push_back(r);
     }
-    g_prof_used.clear();
+    p->used.clear();
     return MST_OK;
 }
 

@@ -43,7 +43,7 @@ class VitWeights(C.Structure):
                 ("compute_dtype", _i), ("grid_h", _i), ("grid_w", _i),
                 ("patch_w", _vp), ("patch_b", _vp), ("prefix", _vp), ("pos_patch", _vp),
                 ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp), ("fp8_linear", _i),
-                ("fp8_amax", _vp), ("fp8_amax_out", _vp)]
+                ("fp8_amax", _vp), ("fp8_amax_out", _vp), ("profiler", _vp)]
 
 
 class FusionWeights(C.Structure):
@@ -51,7 +51,7 @@ class FusionWeights(C.Structure):
                [(n, _vp) for n in ("bottleneck_w", "bottleneck_b", "slice_pos_emb", "cls_token",
                                    "ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b",
                                    "ln2_w", "ln2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
-                                   "norm_w", "norm_b", "rope_freqs", "head_w", "head_b", "liere_rot")]
+                                   "norm_w", "norm_b", "rope_freqs", "head_w", "head_b", "liere_rot")] + [("head_in", _i)]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/mst_hip.h is exported
@@ -78,8 +78,9 @@ SIGNATURES = {
     "mst_saliency_upsample": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "mst_liere_rotation": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_attention_rollout": (_i, [C.POINTER(_vp), _i, _i64, _i, _vp, _vp, _vp]),
-    "mst_profile_enable": (_i, [_i]),
-    "mst_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mst_profiler_create": (_vp, []),
+    "mst_profiler_destroy": (None, [_vp]),
+    "mst_profiler_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
 K_COUNT = 9
@@ -382,14 +383,29 @@ def attention_rollout(maps: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
-def profile_enable(on: bool):
-    _check(load().mst_profile_enable(1 if on else 0), "mst_profile_enable")
+class Profiler:
+    """Caller-owned per-kernel timer (mst_profiler): attach with ``vit.profiler = prof.handle`` (DinoV2ClassifierSlice.profiler)."""
 
+    def __init__(self):
+        self.handle = load().mst_profiler_create()
+        if not self.handle:
+            raise RuntimeError("mst_profiler_create failed")
 
-def profile_collect():
-    """{kind name: (total ms, launches)} since the last collect (waits for the recorded events)."""
-    ms = (C.c_double * K_COUNT)()
-    cnt = (C.c_int64 * K_COUNT)()
-    _check(load().mst_profile_collect(ms, cnt), "mst_profile_collect")
-    lib = load()
-    return {lib.mst_kernel_kind_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(K_COUNT)}
+    def collect(self):
+        """{kind name: (total ms, launches)} since the last collect (waits for the recorded events)."""
+        ms = (C.c_double * K_COUNT)()
+        cnt = (C.c_int64 * K_COUNT)()
+        _check(load().mst_profiler_collect(self.handle, ms, cnt), "mst_profiler_collect")
+        lib = load()
+        return {lib.mst_kernel_kind_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(K_COUNT)}
+
+    def close(self):
+        if self.handle:
+            load().mst_profiler_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

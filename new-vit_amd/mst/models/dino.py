@@ -249,11 +249,21 @@ class DinoV2ClassifierSlice(BasicClassifier):
 
         self._prep = None       # prepared device-side weights (struct + tensors kept alive)
         self._prep_sig = None
+        self._param_epoch = 0
+        self._sentinels = None
+        self.profiler: Optional[hip.Profiler] = None   # bench only: set to a hip.Profiler to time this model's launches
+        self._cls_last = None
+        self._local = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate_prepared())
         self._pos_cache = {}
         self._ws = {}
         self._sharding: Optional[SliceSharding] = None
         self._warned_grad = False
         self._register_load_state_dict_pre_hook(self._remap_state_dict)
+
+    def _invalidate_prepared(self):
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+        self._prep = self._prep_sig = self._sentinels = None
 
     # ---- checkpoint compatibility ---------------------------------------------------------------
     def _remap_state_dict(self, state_dict, prefix, *args):
@@ -270,10 +280,17 @@ class DinoV2ClassifierSlice(BasicClassifier):
                 state_dict[prefix + "encoder.blocks.0." + ".".join(rest)] = state_dict.pop(k)
 
     # ---- multi-GPU: slices of every volume sharded over the ranks of a process group --------------
-    def enable_slice_sharding(self, group=None):
+    def enable_slice_sharding(self, group=None, sharding: Optional[SliceSharding] = None, gather_all_layers: bool = False):
         """Encode slices [r*D/G, (r+1)*D/G) on rank r and all-gather the slice embeddings (RCCL over
-        xGMI) before the replicated Slice Transformer.  Call with the same input on all ranks."""
-        self._sharding = SliceSharding(group)
+        xGMI) before the replicated Slice Transformer.  Call with the same input on all ranks.
+
+        With ``save_attn`` a second all-gather ships the LAST block's CLS rows (2.1 MB at 64 x 518^2: all that
+        ``get_plane_attention`` / ``get_attention_maps`` read, reference dino.py:190); ``attention_maps[:-1]`` then hold
+        this rank's own slices only.  ``gather_all_layers=True`` gathers every block's rows (the unsharded list).
+        ``get_attention_cls`` chains each rank's own full maps and gathers the result.
+        ``sharding``: a prepared transport (tests rehearse several ranks on one GPU with tools/rehearsal.py)."""
+        self._sharding = sharding if sharding is not None else SliceSharding(group)
+        self._gather_all_layers = bool(gather_all_layers)
         return self
 
     def disable_slice_sharding(self):
@@ -304,14 +321,26 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self._fp8_amax = self._fp8_calib = None
         self._fp8_collect = False
 
-    def _signature(self):
-        return (self.compute_dtype_name, str(self.device),
-                None if self._fp8_amax is None else (self._fp8_amax.data_ptr(), self._fp8_amax._version), self._fp8_collect,
-                tuple((p.data_ptr(), p._version) for p in self.parameters()))
+    def _signature(self, full: bool):
+        """Identity of everything ``_prepare`` folded into device-side weight images.  Walking all ~200 parameters costs
+        ~50 us per forward (5 % of the 1.1 ms c1 forward), so with grad disabled the walk is replaced by an epoch counter
+        that every path which can replace or rewrite parameters bumps (``_apply`` = .to/.cuda/.half, ``load_state_dict``)
+        plus the versions of four sentinel tensors; with grad enabled (optimiser steps rewrite in place) all are walked."""
+        head = (self.compute_dtype_name, None if self._fp8_amax is None else (self._fp8_amax.data_ptr(), self._fp8_amax._version),
+                self._fp8_collect, self._param_epoch)
+        ps = list(self.parameters()) if (full or self._sentinels is None) else self._sentinels
+        if self._sentinels is None:
+            self._sentinels = [ps[0], ps[len(ps) // 3], ps[2 * len(ps) // 3], ps[-1]]
+        return head + tuple((q.data_ptr(), q._version) for q in (ps if full else self._sentinels))
+
+    def _apply(self, fn, *args, **kwargs):
+        self._invalidate_prepared()
+        return super()._apply(fn, *args, **kwargs)
 
     def _prepare(self):
-        sig = self._signature()
-        if self._prep is not None and sig == self._prep_sig:
+        full = torch.is_grad_enabled()
+        sig = self._signature(full)
+        if self._prep is not None and sig == self._prep_sig[full]:
             return self._prep
         dev = self.device
         if dev.type != "cuda":
@@ -421,8 +450,9 @@ class DinoV2ClassifierSlice(BasicClassifier):
         else:
             fw.out_ch = self.out_ch
             fw.head_w, fw.head_b = hip.ptr(f32(self.linear.weight)), hip.ptr(f32(self.linear.bias))
+            fw.head_in = self.linear.weight.shape[1]
         self._prep = dict(vit=vit, layers=layers, fusion=fw, keep=keep, pos=pos, cdt=cdt)
-        self._prep_sig = sig
+        self._prep_sig = {True: self._signature(True), False: self._signature(False)}
         self._pos_cache = {}
         return self._prep
 
@@ -472,6 +502,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         vit.grid_h, vit.grid_w = H // PATCH, W // PATCH
         pp = self._pos_patch(prep, H, W)
         vit.pos_patch = hip.ptr(pp)
+        vit.profiler = self.profiler.handle if self.profiler is not None else None
         enc = self.encoder
         E, heads = enc.embed_dim, enc.num_heads
         N = 1 + enc.num_register_tokens + vit.grid_h * vit.grid_w
@@ -493,6 +524,9 @@ class DinoV2ClassifierSlice(BasicClassifier):
         fw = prep["fusion"]
         dev = emb.device
         F = self.emb_ch * D if self.slice_fusion_type == "linear" else self.emb_ch
+        if want_logits and F != self.linear.weight.shape[1]:     # what nn.Linear raises in the reference (dino.py:166)
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{F} and "
+                               f"{self.linear.weight.shape[1]}x{self.linear.weight.shape[0]})")
         features = torch.empty((B, F), dtype=torch.float32, device=dev)
         logits = torch.empty((B, self.out_ch), dtype=torch.float32, device=dev) if want_logits else None
         probs = None
@@ -526,26 +560,41 @@ class DinoV2ClassifierSlice(BasicClassifier):
             n_probs = self.encoder.depth
         want_full = bool(save_attn and self.full_attention_maps)
 
+        without_linear = bool(kwargs.get("without_linear", False))
+        want_logits = (not without_linear) and not isinstance(self.linear, nn.Identity)
+        if want_logits and self.slice_fusion_type == "linear" and D * self.emb_ch != self.linear.weight.shape[1]:
+            # nn.Linear's complaint in the reference (dino.py:155,166: the head is built for 32 slices), before any GPU work
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{D * self.emb_ch} and "
+                               f"{self.linear.weight.shape[1]}x{self.linear.weight.shape[0]})")
+        self._local = None                              # (d0, d1, dpad): this rank's slices when the maps below are sharded
         if self._sharding is not None and self._sharding.world_size > 1:
             sh = self._sharding
             d0, d1, dpad = sh.shard_range(D)
+            dl = d1 - d0
             local = slices[:, d0:d1]
-            if d1 - d0 < dpad:                          # equal-sized shards for the collective
-                local = torch.cat([local, local.new_zeros(B, dpad - (d1 - d0), H, W)], dim=1)
+            if dl < dpad:                               # equal-sized shards for the collective
+                local = torch.cat([local, local.new_zeros(B, dpad - dl, H, W)], dim=1)
             emb_l, probs_l, full_l = self.encode_slices(local.reshape(B * dpad, H, W).contiguous(), n_probs, want_full)
             emb = sh.all_gather_slices(emb_l.view(B, dpad, -1), D).reshape(B * D, -1)
-            cls_probs = full_probs = None
-            if probs_l is not None:                     # [12, B*dpad, h, N] -> gather along the slice axis
+            cls_probs = full_probs = cls_last = None
+            if probs_l is not None:                     # [12, B*dpad, h, N]: gather along the slice axis
                 Lp, _, hh, NN = probs_l.shape
-                g = sh.all_gather_slices(probs_l.view(Lp, B, dpad, hh * NN).permute(1, 2, 0, 3).reshape(B, dpad, Lp * hh * NN), D)
-                cls_probs = g.view(B, D, Lp, hh, NN).permute(2, 0, 1, 3, 4).reshape(Lp, B * D, hh, NN).contiguous()
-            if full_l is not None:
-                raise NotImplementedError("full_attention_maps is not supported together with slice sharding")
+                if getattr(self, "_gather_all_layers", False):
+                    g = sh.all_gather_slices(probs_l.view(Lp, B, dpad, hh * NN).permute(1, 2, 0, 3).reshape(B, dpad, Lp * hh * NN), D)
+                    cls_probs = g.view(B, D, Lp, hh, NN).permute(2, 0, 1, 3, 4).reshape(Lp, B * D, hh, NN).contiguous()
+                    cls_last = cls_probs[-1]
+                else:                                   # only the last block's rows are read by the getters (dino.py:190)
+                    cls_last = sh.all_gather_slices(probs_l[-1].view(B, dpad, hh * NN), D).view(B * D, hh, NN)
+                    cls_probs = probs_l.view(Lp, B, dpad, hh, NN)[:, :, :dl].reshape(Lp, B * dl, hh, NN)
+                    self._local = (d0, d1, dpad)
+            if full_l is not None:                      # [12, B*dpad, h, N, N] stays on its rank (34.6 GB unsharded at c3)
+                Lp = full_l.shape[0]
+                full_probs = full_l.view(Lp, B, dpad, *full_l.shape[2:])[:, :, :dl].reshape(Lp, B * dl, *full_l.shape[2:])
+                self._local = (d0, d1, dpad)
         else:
             emb, cls_probs, full_probs = self.encode_slices(slices.reshape(B * D, H, W).contiguous(), n_probs, want_full)
+            cls_last = cls_probs[-1] if cls_probs is not None else None
 
-        without_linear = bool(kwargs.get("without_linear", False))
-        want_logits = (not without_linear) and not isinstance(self.linear, nn.Identity)
         features, logits, slice_probs = self.fuse_slices(emb, B, D, src_key_padding_mask, bool(save_attn), want_logits)
 
         if save_attn:
@@ -555,6 +604,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
                 self.attention_maps = [cls_probs[l][:, :, None, :] for l in range(cls_probs.shape[0])]
             if slice_probs is not None:
                 self.attention_maps_slice = [slice_probs]
+            self._cls_last = cls_last                     # [B*D, h, N] of ALL slices (gathered when sharded)
         self._last_shape = (B, D)
         return logits if want_logits else features
 
@@ -562,7 +612,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
     def _readout(self, plane=False, slice_attn=False, maps=False):
         B, D = self._last_shape
         enc = self.encoder
-        cls_last = self.attention_maps[-1][:, :, 0].contiguous() if (plane or maps) else None   # [n,h,N]
+        cls_last = self._cls_last.contiguous() if (plane or maps) else None                      # [n,h,N]
         sp = self.attention_maps_slice[-1].contiguous() if (slice_attn or maps) else None
         dev = (cls_last if cls_last is not None else sp).device
         R = 4 if self.use_registers else 0            # img_slice = slice(5, None): dino.py:191
@@ -586,13 +636,26 @@ class DinoV2ClassifierSlice(BasicClassifier):
         _, _, m = self._readout(maps=True)
         return m                                       # [B*D, heads, Np]
 
-    def get_attention_cls(self):
+    def get_attention_cls(self, gather: bool = True):
         """Attention rollout A_0 . A_1 ... A_last over the full maps (reference dino.py:204-212; no caller
-        in the reference).  Needs ``full_attention_maps=True`` at construction."""
+        in the reference).  Needs ``full_attention_maps=True`` at construction.  Under slice sharding every rank chains
+        the maps of its own slices (the chain is independent per slice and head) and the result is all-gathered to
+        ``[B*D, heads, N, N]`` on every rank; ``gather=False`` returns this rank's ``[B*d_local, heads, N, N]``."""
         if not self.attention_maps or self.attention_maps[-1].shape[-2] != self.attention_maps[-1].shape[-1]:
             raise RuntimeError("get_attention_cls needs the full [n,h,N,N] maps: construct the model with "
                                "full_attention_maps=True and run forward(save_attn=True)")
-        return hip.attention_rollout([m.contiguous() for m in self.attention_maps])   # [B*D, heads, N, N]
+        maps = [m.contiguous() for m in self.attention_maps]
+        if self._local is None or not gather:
+            if maps[0].shape[0] == 0:
+                return maps[0].clone()
+            return hip.attention_rollout(maps)                                        # [B*D, heads, N, N]
+        B, D = self._last_shape
+        d0, d1, dpad = self._local
+        _, hh, NN, _ = maps[0].shape
+        padded = maps[0].new_zeros((B, dpad, hh * NN * NN))
+        if d1 > d0:
+            padded[:, : d1 - d0] = hip.attention_rollout(maps).view(B, d1 - d0, -1)
+        return self._sharding.all_gather_slices(padded, D).view(B * D, hh, NN, NN)
 
 
 class DinoV3ClassifierSlice(BasicClassifier):

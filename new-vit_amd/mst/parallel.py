@@ -5,7 +5,7 @@ is new design for MI355X.  Slices are independent through the whole ViT and only
 Transformer mixes them, so rank r of G encodes slices [r*ceil(D/G), (r+1)*ceil(D/G)) of every
 volume and ONE all-gather of the slice embeddings ([B, D/G, E] fp32: 98 KB per volume at D=64)
 precedes the replicated fusion stage.  The message is latency-bound, so it is issued as a single
-``all_gather_into_tensor`` (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).
+``all_gather_into_tensor`` (RCCL over xGMI with backend "nccl"; gloo on CPU tensors in the tests).
 Pure tensor plumbing: no arithmetic lives here.
 """
 from __future__ import annotations
@@ -28,18 +28,16 @@ class SliceSharding:
         """(first slice, one-past-last slice, padded shard length) of this rank."""
         return shard_range(D, self.world_size, self.rank)
 
+    def _all_gather(self, out: torch.Tensor, local: torch.Tensor):
+        """One collective on tensors of the group's backend (device tensors over RCCL)."""
+        dist.all_gather_into_tensor(out, local, group=self.group)    # rank-major concatenation on dim 0
+
     def all_gather_slices(self, local: torch.Tensor, D: int) -> torch.Tensor:
         """local [B, dpad, X] (this rank's shard, zero-padded to dpad) -> [B, D, X] on every rank."""
         B, dpad, X = local.shape
         local = local.contiguous()
-        dev = local.device
-        if dev.type == "cuda" and dist.get_backend(self.group) == "gloo":
-            # rehearsal only (several ranks on ONE GPU, where RCCL refuses duplicate devices): gloo has no CUDA
-            # all_gather, so the 100-KB message takes the host path.  The product path is backend "nccl" (= RCCL).
-            local = local.cpu()
         out = torch.empty((self.world_size * B, dpad, X), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=self.group)  # rank-major concatenation on dim 0
-        out = out.to(dev)
+        self._all_gather(out, local)
         out = out.view(self.world_size, B, dpad, X)
         return out.permute(1, 0, 2, 3).reshape(B, self.world_size * dpad, X)[:, :D].contiguous()
 

@@ -282,10 +282,20 @@ def forward(sd: SD, source: Tensor, *, model_size: str = "s", slice_fusion_type:
     Returns dict(logits|features, emb [B*D,E], vit_maps list, slice_map [B,12,L,L] or None)."""
     B, C, D, H, W = source.shape
     emb, maps = vit_encode(sd, source.permute(0, 2, 1, 3, 4).reshape(B * D * C, H, W), model_size, keep, linear)   # l.125-131
+    out = fuse(sd, emb, B, D * C, slice_fusion_type=slice_fusion_type, src_key_padding_mask=src_key_padding_mask,
+               rotary=rotary, without_linear=without_linear)
+    out["vit_maps"] = maps
+    return out
+
+
+def fuse(sd: SD, emb: Tensor, B: int, D: int, *, slice_fusion_type: str = "transformer",
+         src_key_padding_mask: Optional[Tensor] = None, rotary: Optional[str] = None,
+         without_linear: bool = False) -> Dict[str, Tensor]:
+    """Everything of DinoV2ClassifierSlice.forward after the encoder (dino.py:134-166) on slice embeddings emb [B*D, E]."""
     x = emb
     if "bottleneck.weight" in sd:                                                    # l.134-135
         x = F.linear(x, sd["bottleneck.weight"], sd["bottleneck.bias"])
-    x = x.reshape(B, D * C, -1)                                                      # l.138
+    x = x.reshape(B, D, -1)                                                          # l.138
     if "slice_pos_emb.weight" in sd:                                                 # l.140-142
         x = x + sd["slice_pos_emb.weight"][: x.shape[1]]
     slice_map = None
@@ -300,7 +310,7 @@ def forward(sd: SD, source: Tensor, *, model_size: str = "s", slice_fusion_type:
         x = x.reshape(B, -1)
     elif slice_fusion_type == "average":
         x = x.mean(dim=1)
-    out = {"emb": emb, "vit_maps": maps, "slice_map": slice_map, "features": x}
+    out = {"emb": emb, "slice_map": slice_map, "features": x}
     if not without_linear and "linear.weight" in sd:                                 # l.164-166
         out["logits"] = F.linear(x, sd["linear.weight"], sd["linear.bias"])
     return out

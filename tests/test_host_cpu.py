@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_library_exports_every_header_symbol():
     from mst import hip
     header = (ROOT / "include" / "mst_hip.h").read_text()
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(mst_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|void|const char\*|mst_profiler\*)\s+(mst_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared, "no entry points parsed from include/mst_hip.h"
     lib = hip.load()                                  # raises if the .so is missing: no fallback
     for sym in sorted(declared):
@@ -215,3 +215,30 @@ def test_oracle_fp8_calibrated_table_reproduces_the_dynamic_run():
         half, _ = O.vit_encode(sd, x, "s", linear="fp8", act_amax=(torch.tensor(table) * 0.5).tolist())
     assert torch.equal(sta, dyn)
     assert not torch.equal(half, dyn)                       # a too-tight table saturates the largest values
+
+
+def test_bench_flop_model_matches_the_oracle_and_survey():
+    """bench.py owns its FLOP model (SURVEY.md 8d formula); the oracle's restatement of it must agree."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from oracle import mst_oracle as O
+    for D, H, W in ((16, 224, 224), (64, 518, 518), (96, 518, 518), (4, 504, 280)):
+        assert abs(bench.flops_per_volume(D, H, W) - O.flops_per_volume(D, H, W)) < 1e-6 * O.flops_per_volume(D, H, W)
+    assert abs(bench.flops_per_slice(518, 518) - 93.39e9) < 0.01e9          # BASELINE.md section 3
+    assert abs(bench.flops_per_volume(64, 518, 518) - 5.977e12) < 0.001e12
+
+
+def test_bench_gpus_n_without_devices_fails_loudly():
+    """`python bench.py --gpus 2` must start ranks itself or exit non-zero -- never report n_gpus 1.  No GPU here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MST_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 requested but only" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE 4" in r.stderr

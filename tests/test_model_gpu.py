@@ -35,13 +35,13 @@ CASES = {
 }
 
 
-# The LieRE slice transformer (33 tokens re-partitioned into pseudo-heads) amplifies a given embedding error about
-# 2-4x more into the logits than the other fusions do (tools/fixture_errors.py: same 1.8e-3 embedding error in fp16,
-# 5.6e-3 on the logits vs <= 2.9e-3 elsewhere), so its logits tolerance is doubled in the 16-bit modes only.
-# 'linear' fusion feeds all D*E = 12,288 slice features straight into the head: the same per-feature error sums over 32x
-# more terms than a CLS read-out (measured 2.5e-2 .. 3.2e-2 in bf16 across kernel revisions at an unchanged 1.4e-2 embedding
-# error, against <= 1.6e-2 for the transformer fusions).
-LOGIT_SCALE = {"liere": {"fp16": 2.0, "bf16": 2.0}, "linear32": {"fp16": 2.0, "bf16": 2.0}}
+# The across-slice stage (bottleneck .. head) runs in fp32 in every mode, so whatever the logits deviate by is the encoder's
+# embedding error carried through it.  Every case therefore checks the stage in isolation -- the HIP logits against the
+# oracle's fusion of the HIP embeddings, at the fp32 bar -- and the fixture comparison of the two cases whose fusion amplifies
+# that error (LieRE's 33 re-partitioned tokens; 'linear' summing 12,288 features into the head) is bounded by the error the
+# oracle itself propagates from those embeddings instead of by a widened constant.
+PROPAGATED = ("liere", "linear32")
+STAGE_TOL = 2e-4
 
 
 def build(name_kwargs, seed, mode, **extra):
@@ -62,7 +62,6 @@ def build(name_kwargs, seed, mode, **extra):
 def test_forward_matches_reference_fixture(name, mode):
     g = load_golden(name)
     tl, te, tm = TOL[mode]
-    tl *= LOGIT_SCALE.get(name, {}).get(mode, 1.0)
     model = build(CASES[name], int(g["seed"]), mode)
     src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
     mask = torch.from_numpy(g["src_key_padding_mask"]) if "src_key_padding_mask" in g else None
@@ -70,12 +69,28 @@ def test_forward_matches_reference_fixture(name, mode):
         logits = model(src, src_key_padding_mask=mask)                 # CPU input: forward moves it (dino.py:121)
         feats = model(src.cuda(), src_key_padding_mask=mask, without_linear=True)
     assert logits.shape == g["logits"].shape and logits.is_cuda
-    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tl
-    assert rel_l2(feats.cpu(), g["features"]) < te * 2
     B, _, D, H, W = src.shape
     with torch.no_grad():
         emb, _, _ = model.encode_slices(src.cuda().reshape(B * D, H, W))
     assert rel_l2(emb.cpu(), g["emb"]) < te
+    # the fp32 across-slice stage alone: HIP logits vs the oracle's fusion of the HIP embeddings
+    from oracle import mst_oracle as O
+    kw = CASES[name]
+    sd = synth.synth_state_dict(kw.get("model_size", "s"), int(g["seed"]), use_bottleneck=kw.get("use_bottleneck", False),
+                                use_slice_pos_emb=kw.get("use_slice_pos_emb", False),
+                                slice_fusion=kw.get("slice_fusion", "transformer"), rotary=kw.get("rotary_positional_encoding"))
+    with torch.no_grad():
+        staged = O.fuse(sd, emb.cpu(), B, D, slice_fusion_type=kw.get("slice_fusion", "transformer"),
+                        src_key_padding_mask=mask, rotary=kw.get("rotary_positional_encoding"))
+    stage_err = float((logits.cpu() - staged["logits"]).abs().max())
+    assert stage_err < STAGE_TOL, stage_err
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    if name in PROPAGATED and mode != "fp32":
+        propagated = float((staged["logits"] - torch.from_numpy(g["logits"])).abs().max())   # embedding error through the exact stage
+        assert err <= propagated + STAGE_TOL, (err, propagated)
+    else:
+        assert err < tl, err
+    assert rel_l2(feats.cpu(), g["features"]) < te * 2
     if "attention_maps" not in g:
         return
     with torch.no_grad():
@@ -154,6 +169,13 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(AssertionError) as e:
         DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="l")
     assert str(e.value) == ref["model_size_l"]["message"]
+    # 'linear' fusion: the head is nn.Linear(32 * emb, out) (dino.py:245), so any D != 32 is nn.Linear's shape error
+    lin = build(dict(slice_fusion="linear"), 5, "fp32")
+    for D in (16, 48):
+        with pytest.raises(RuntimeError, match="shapes cannot be multiplied"), torch.no_grad():
+            lin(torch.zeros(1, 1, D, 28, 28))
+    with torch.no_grad():
+        assert lin(torch.zeros(1, 1, D, 28, 28), without_linear=True).shape == (1, D * 384)   # features alone have no such limit
 
 
 def test_hub_layout_layerscale_registers_against_oracle():
@@ -212,27 +234,61 @@ def test_liere_restrictions_raise_like_the_reference():
 
 def _shard_worker(rank, world, port, ret):
     import os
+    import sys
     import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, str(ROOT / "tools"))
+    from rehearsal import HostStagedSharding              # both ranks share cuda:0: RCCL refuses duplicate devices
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share cuda:0: RCCL refuses duplicate devices
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     g = load_golden("b2_mask")
     model = build(CASES["b2_mask"], int(g["seed"]), "fp16")
     src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
     mask = torch.from_numpy(g["src_key_padding_mask"])
+    res = {}
     with torch.no_grad():
         ref = model(src, src_key_padding_mask=mask, save_attn=True)
-        ref_maps = model.get_attention_maps()
-        model.enable_slice_sharding()
-        out = model(src, src_key_padding_mask=mask, save_attn=True)      # D = 6 over 2 ranks; with 4 ranks it would be ragged
-        maps = model.get_attention_maps()
-    ret[rank] = (bool(torch.equal(out, ref)), bool(torch.equal(maps, ref_maps)), float((out.cpu() - torch.from_numpy(g["logits"])).abs().max()))
+        ref_maps, ref_plane = model.get_attention_maps(), model.get_plane_attention()
+        ref_rows = torch.stack([m[:, :, 0] for m in model.attention_maps])
+        model.enable_slice_sharding(sharding=HostStagedSharding())
+        out = model(src, src_key_padding_mask=mask, save_attn=True)      # D = 6 over 2 ranks
+        res["logits"] = bool(torch.equal(out, ref))
+        res["maps"] = bool(torch.equal(model.get_attention_maps(), ref_maps) and torch.equal(model.get_plane_attention(), ref_plane))
+        # only the LAST block's rows travel; the earlier list entries are this rank's own slices
+        B, D = 2, 6
+        d0, d1, _ = model._sharding.shard_range(D)
+        own = ref_rows.view(12, B, D, *ref_rows.shape[2:])[:, :, d0:d1].reshape(12, B * (d1 - d0), *ref_rows.shape[2:])
+        res["own_rows"] = bool(torch.equal(torch.stack([m[:, :, 0] for m in model.attention_maps]), own))
+        model.enable_slice_sharding(sharding=HostStagedSharding(), gather_all_layers=True)
+        model(src, src_key_padding_mask=mask, save_attn=True)
+        res["all_rows"] = bool(torch.equal(torch.stack([m[:, :, 0] for m in model.attention_maps]), ref_rows))
+    res["err"] = float((out.cpu() - torch.from_numpy(g["logits"])).abs().max())
+
+    # rollout (get_attention_cls, dino.py:204-212) under sharding: D = 3 over 2 ranks is an UNEVEN split (2 + 1 slices)
+    g = load_golden("rollout_1x3x84")
+    model = build({}, int(g["seed"]), "fp32", full_attention_maps=True)
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    with torch.no_grad():
+        ref = model(src, save_attn=True)
+        ref_roll = model.get_attention_cls()
+        model.enable_slice_sharding(sharding=HostStagedSharding())
+        out = model(src, save_attn=True)
+        roll = model.get_attention_cls()
+        local = model.get_attention_cls(gather=False)
+    d0, d1, _ = model._sharding.shard_range(3)
+    res["roll_logits"] = bool(torch.equal(out, ref))
+    res["roll"] = bool(torch.equal(roll, ref_roll))
+    res["roll_local"] = bool(torch.equal(local, ref_roll[d0:d1]))
+    res["roll_err"] = rel_l2(roll.cpu(), g["attention_cls"])
+    ret[rank] = res
     dist.destroy_process_group()
 
 
 def test_slice_sharded_forward_equals_unsharded_two_ranks_one_gpu():
     """slices sharded over ranks + all-gather of embeddings / CLS rows must reproduce the single-rank
-    forward bit-for-bit (slices are independent in the encoder; the fusion stage is replicated)."""
+    forward bit-for-bit (slices are independent in the encoder; the fusion stage is replicated) -- logits, attention
+    read-outs and the sharded rollout (BASELINE configs[2]: `--get_attention` rollout with slices sharded)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -243,9 +299,34 @@ def test_slice_sharded_forward_equals_unsharded_two_ranks_one_gpu():
         p.join(300)
         assert p.exitcode == 0
     for r in range(2):
-        same_logits, same_maps, err = ret[r]
-        assert same_logits and same_maps, (r, ret[r])
-        assert err < TOL["fp16"][0]
+        res = ret[r]
+        for key in ("logits", "maps", "own_rows", "all_rows", "roll_logits", "roll", "roll_local"):
+            assert res[key], (r, key, res)
+        assert res["err"] < TOL["fp16"][0]
+        assert res["roll_err"] < TOL["fp32"][2]
+
+
+def test_full_bench_batch_matches_single_volume_and_reference_fixture():
+    """BASELINE configs[1] at full size: 4 x 64 x 518^2 in bf16, one launch sequence over 350,720 tokens.  Volume 0 is the
+    input of the reference fixture c3_1x64x518: its logits / embeddings inside the batch must be bit-equal to the
+    single-volume run (slices are independent rows of every kernel) and within the bf16 bar of what the reference produced."""
+    g = load_golden("c3_1x64x518")
+    tl, te, _ = TOL["bf16"]
+    model = build({}, int(g["seed"]), "bf16")
+    gen = torch.Generator().manual_seed(7)
+    vols = torch.randn((4, 1, 64, 518, 518), generator=gen)
+    vols[0] = synth.synth_volume((1, 1, 64, 518, 518), int(g["seed"]) + 100)[0]
+    vols = vols.to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        batch = model(vols)
+        single = model(vols[:1])
+        emb_b, _, _ = model.encode_slices(vols.reshape(256, 518, 518))
+        emb_s, _, _ = model.encode_slices(vols[0].reshape(64, 518, 518))
+        last = model(vols[3:])
+    assert torch.equal(batch[:1], single) and torch.equal(batch[3:], last)
+    assert torch.equal(emb_b[:64], emb_s)
+    assert np.abs(batch[:1].cpu().numpy() - g["logits"]).max() < tl
+    assert rel_l2(emb_b[:64].cpu(), g["emb"]) < te
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp16"])

@@ -9,9 +9,8 @@ from mst import hip
 vol = torch.randn(4,1,64,518,518, device="cuda").bfloat16()
 with torch.no_grad():
     for _ in range(2): model(vol)
-    hip.profile_enable(True)
+    model.profiler = hip.Profiler()
     for _ in range(5): model(vol)
     torch.cuda.synchronize()
-    hip.profile_enable(False)
-p = hip.profile_collect()
+p = model.profiler.collect()
 print({k: round(v[0]/max(v[1],1),4) for k,v in p.items() if v[1]})
