@@ -3,9 +3,11 @@ REFERENCE produced (tests/golden, tools/gen_golden.py) and against the CPU oracl
 
 Tolerances (floating point; north_star: logits / attention maps within 1e-3 in fp32):
   fp32 mode  (exact fp32 MFMA)            logits 1e-4 abs, embeddings 2e-4 rel-L2, maps 1e-3 rel-L2
-  fp16 mode  (TF32-class operands)        logits 5e-3 abs, embeddings 3e-3 rel-L2, maps 2e-2 rel-L2
-  bf16 mode  (bench dtype, 8-bit mantissa) logits 3e-2 abs, embeddings 3e-2 rel-L2, maps 1.5e-1 rel-L2
+  fp16 mode  (TF32-class operands)        logits 5e-3 abs, embeddings 3e-3 rel-L2, maps 1e-2 rel-L2
+  bf16 mode  (bench dtype, 8-bit mantissa) logits 3e-2 abs, embeddings 3e-2 rel-L2, maps 7e-2 rel-L2
 Attention maps are compared relatively (entries are ~1/(D*Np): an absolute 1e-3 would be vacuous).
+The 16-bit bars are <= 2x the worst error measured over all fixtures (tools/fixture_errors.py, profiles/r02a_fixture_errors.txt:
+fp16 logits 3.2e-3 / emb 1.9e-3 / maps 4.7e-3; bf16 logits 2.1e-2 / emb 1.45e-2 / maps 3.5e-2).
 """
 import json
 
@@ -20,8 +22,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = {  # mode -> (logits abs, emb rel, maps rel)
     "fp32": (1e-4, 2e-4, 1e-3),
-    "fp16": (5e-3, 3e-3, 2e-2),
-    "bf16": (3e-2, 3e-2, 1.5e-1),
+    "fp16": (5e-3, 3e-3, 1e-2),
+    "bf16": (3e-2, 3e-2, 7e-2),
 }
 CASES = {
     "c1_1x16x224": dict(),
