@@ -261,8 +261,6 @@ def main():
             launch_slices = slices_per_rank * sampled_steps * (DEPTH if kind not in ("patch_embed",) else 1) / cnt
             avg_ms = ms / cnt
             kname = kind
-            if kind == "mlp_fused" and "gemm_proj" not in kernels and getattr(model, "proj_folded", False):
-                kname = "block_fused"
             fl = kernel_flops(kname, int(round(launch_slices)), N)
             kernels[kname] = {"total_ms": round(ms, 3), "launches": cnt, "avg_ms": round(avg_ms, 4),
                               "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 1) if fl else None}

@@ -139,6 +139,19 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
 int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const float* b1f, const float* b2f,
                   int64_t M, int E, float eps, mst_stream_t stream);
 
+/* Everything of a ViT block after the attention kernel in ONE launch (E = 384, 16-bit operands): the out-projection
+ * (attention.py:67-68) + residual (block.py:90-91,112), then the fused MLP half exactly as mst_mlp_fused:
+ *   x[M,E] (fp32, in place) += ls1 * (proj(attn_out) + b_proj);  x += ls2 * (fc2(gelu(fc1(normalise(x)))) + b2);
+ *   xn_out (nullable, dtype; MAY alias attn_out) = normalise(x_new)
+ * x is read once and written once.  attn_out [M,E] dtype.  proj_pack: 12 chunks x 24576 B, chunk j = LDS image
+ *   [R 0..383][slot 0..3][8] = ls1[n(R)] * proj_w[n(R)][32j + 8(slot^f(R)) ..+7]   (n, f as in mst_mlp_fused),
+ * proj_bf fp32 [E] = ls1 * proj_b (ls1 = 1 when absent); wpack / b1f / b2f as mst_mlp_fused.  scratch: at least
+ * mst_block_fused_scratch_bytes() (96 KiB per compute unit: the LayerNorm2 hand-off between the kernel's wave roles). */
+size_t mst_block_fused_scratch_bytes(void);
+int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, const void* proj_pack, const float* proj_bf,
+                    const void* wpack, const float* b1f, const float* b2f, void* scratch, size_t scratch_bytes, int64_t M,
+                    int E, float eps, mst_stream_t stream);
+
 /* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only).  A caller-owned object:
  * while mst_vit_weights.profiler points at one, every launch of that call is bracketed by hipEventRecord on the call's own
  * stream; mst_profiler_collect waits for the recorded events, returns the accumulated milliseconds and launch counts per
@@ -147,7 +160,8 @@ typedef struct mst_profiler mst_profiler;
 enum mst_kernel_kind {
     MST_K_PATCH_EMBED = 0, MST_K_LAYERNORM = 1, MST_K_GEMM_QKV = 2, MST_K_ATTENTION = 3,
     MST_K_GEMM_PROJ = 4, MST_K_GEMM_FC1 = 5, MST_K_GEMM_FC2 = 6, MST_K_CLS_PROBS = 7, MST_K_MLP_FUSED = 8,
-    MST_K_COUNT = 9
+    MST_K_BLOCK_FUSED = 9,        /* out-projection + MLP in one launch (mst_block_fused) */
+    MST_K_COUNT = 10
 };
 mst_profiler* mst_profiler_create(void);
 void mst_profiler_destroy(mst_profiler* p);
@@ -170,6 +184,8 @@ typedef struct mst_vit_layer {
      *   mlp_pack / fc1_bf / fc2_bf: see mst_mlp_fused                        (norm2 and ls2 folded) */
     const void* qkv_wf; const float* qkv_bf;
     const void* mlp_pack; const float* fc1_bf; const float* fc2_bf;
+    /* with proj_pack / proj_bf (see mst_block_fused) also present for every layer the out-projection joins that launch */
+    const void* proj_pack; const float* proj_bf;
     /* Optional FP8 form (mst_vit_weights.fp8_linear): the four block weights as e4m3 bytes, same [out,in] layout, with their
      * per-tensor scales w8_scale[] = max|W|/448 in the order qkv, proj, fc1, fc2 (see mst_gemm_fp8) */
     const void* qkv_w8; const void* proj_w8; const void* fc1_w8; const void* fc2_w8;

@@ -63,7 +63,7 @@ struct mst_profiler {
 };
 namespace {
 const char* const kKindNames[MST_K_COUNT] = {"patch_embed", "layernorm", "gemm_qkv", "attention",
-                                             "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs", "mlp_fused"};
+                                             "gemm_proj", "gemm_fc1", "gemm_fc2", "cls_probs", "mlp_fused", "block_fused"};
 struct ProfScope {
     mst_profiler* p;
     mst_profiler::Rec r{};
@@ -170,6 +170,16 @@ int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const fl
     return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2f, M, E, eps, (hipStream_t)stream);
 }
 
+size_t mst_block_fused_scratch_bytes(void) { return block16_scratch_bytes(); }
+
+int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, const void* proj_pack, const float* proj_bf,
+                    const void* wpack, const float* b1f, const float* b2f, void* scratch, size_t scratch_bytes, int64_t M,
+                    int E, float eps, mst_stream_t stream) {
+    MST_CHECK_ARG(x && attn_out && proj_pack && proj_bf && wpack && b1f && b2f && scratch, "block_fused: null pointer");
+    MST_CHECK_ARG(scratch_bytes >= block16_scratch_bytes(), "block_fused: scratch %zu < %zu bytes", scratch_bytes, block16_scratch_bytes());
+    return launch_block16(x, attn_out, xn_out, dtype, proj_pack, proj_bf, wpack, b1f, b2f, scratch, M, E, eps, (hipStream_t)stream);
+}
+
 // ---- per-slice encoder ----------------------------------------------------------------------
 // workspace carve (chunk of C slices, Mc = C*N rows):
 //   x   fp32 [Mc, E]      residual stream
@@ -177,7 +187,7 @@ int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const fl
 //   big T    [Mc, 4E]     qkv [Mc, 3E] during attention, then the MLP hidden [Mc, 4E]
 //   fp8_linear only:  a8 u8 [Mc, 4E] (the quantised input of the current GEMM) | amax f32 [depth][4]
 static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn, size_t* off_big, size_t* total,
-                      size_t* off_a8 = nullptr, size_t* off_amax = nullptr) {
+                      size_t* off_a8 = nullptr, size_t* off_amax = nullptr, size_t* off_blk = nullptr) {
     const size_t Mc = (size_t)chunk * N, E = (size_t)w->embed_dim, ts = dt_size(w->compute_dtype);
     size_t o = 0;
     o += align_up(Mc * E * 4, 256);
@@ -191,6 +201,8 @@ static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn
         if (off_amax) *off_amax = o;
         o += align_up((size_t)w->depth * 4 * sizeof(float), 256);
     }
+    if (off_blk) *off_blk = o;
+    o += align_up(block16_scratch_bytes(), 256);        // lane-private LayerNorm2 hand-off of the fused block kernel (96 KiB per CU)
     *total = o;
 }
 
@@ -219,8 +231,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
     MST_CHECK_ARG(n_layers_probs >= 0 && n_layers_probs <= w->depth, "vit_encode: n_layers_probs=%d", n_layers_probs);
     const int R = w->num_registers, Np = w->grid_h * w->grid_w, N = 1 + R + Np;
     if (chunk_slices > n_slices) chunk_slices = n_slices;
-    size_t off_xn, off_big, total, off_a8 = 0, off_amax = 0;
-    vit_carve(w, N, chunk_slices, &off_xn, &off_big, &total, &off_a8, &off_amax);
+    size_t off_xn, off_big, total, off_a8 = 0, off_amax = 0, off_blk = 0;
+    vit_carve(w, N, chunk_slices, &off_xn, &off_big, &total, &off_a8, &off_amax, &off_blk);
     if (ws_bytes < total) {
         mst_set_error("vit_encode: workspace %zu < %zu bytes", ws_bytes, total);
         return MST_EWORKSPACE;
@@ -273,6 +285,10 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         bool fused = !fp8 && (dt != MST_F32) && E == 384 && (int64_t)n_slices * N >= fused_min_tokens;
         for (int l = 0; l < w->depth && fused; ++l)
             fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
+        // out-projection folded into the same launch (k_block16.hip) when its packed image is there (MST_NO_PROJ_FOLD=1: A/B switch)
+        static const bool no_fold = getenv("MST_NO_PROJ_FOLD") && atoi(getenv("MST_NO_PROJ_FOLD"));
+        bool folded = fused && !no_fold;
+        for (int l = 0; l < w->depth && folded; ++l) folded = w->layers[l].proj_pack && w->layers[l].proj_bf;
         if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
         if (fp8 && !fp8_static && hipMemsetAsync(amax, 0, (size_t)w->depth * 4 * sizeof(float), s) != hipSuccess) {
             mst_set_error("vit_encode: hipMemsetAsync(amax) failed");
@@ -326,6 +342,12 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, nullptr, s));
                 RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, 0, s));
                 RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, nullptr, s));
+                continue;
+            }
+            if (folded) {
+                // x += ls1(proj(attn)); x += ls2(fc2(gelu(fc1(norm2 x)))); xn = normalise(x): one launch, x read and written once
+                RUNK(MST_K_BLOCK_FUSED, launch_block16(x, xn, (l + 1 < w->depth) ? xn : nullptr, dt, L->proj_pack, L->proj_bf, L->mlp_pack,
+                                                     L->fc1_bf, L->fc2_bf, (char*)ws + off_blk, Mc, E, 1e-6f, s));
                 continue;
             }
             RUNK(MST_K_GEMM_PROJ, mst_gemm(xn, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, E, Mc, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));

@@ -34,7 +34,7 @@ _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
-                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf",
+                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf", "proj_pack", "proj_bf",
                                    "qkv_w8", "proj_w8", "fc1_w8", "fc2_w8")] + [("w8_scale", C.c_float * 4)]
 
 
@@ -68,6 +68,8 @@ SIGNATURES = {
     "mst_attention_probs_full": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp": (_i, [_vp, _i, _i, _i, _i, _d, _i, _vp, _vp]),
     "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "mst_block_fused_scratch_bytes": (_sz, []),
+    "mst_block_fused": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _f, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
     "mst_vit_encode": (_i, [C.POINTER(VitWeights), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -83,7 +85,7 @@ SIGNATURES = {
     "mst_profiler_collect": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
-K_COUNT = 9
+K_COUNT = 10
 
 _lib: Optional[C.CDLL] = None
 
@@ -265,6 +267,44 @@ def mlp_fused(x: torch.Tensor, wpack: torch.Tensor, b1f: torch.Tensor, b2f: torc
     M, E = x.shape
     _check(load().mst_mlp_fused(ptr(x), ptr(xn_out), _DT[dtype], ptr(wpack), ptr(b1f), ptr(b2f), M, E, eps,
                                 stream_of(x)), "mst_mlp_fused")
+
+
+def block_fused(x: torch.Tensor, attn_out: torch.Tensor, proj_pack: torch.Tensor, proj_bf: torch.Tensor, wpack: torch.Tensor,
+                b1f: torch.Tensor, b2f: torch.Tensor, xn_out: Optional[torch.Tensor], eps: float = 1e-6,
+                scratch: Optional[torch.Tensor] = None):
+    """mst_block_fused: x [M,384] fp32 in place += ls1*proj(attn_out) then += the fused MLP; xn_out (may be attn_out itself)
+    receives normalise(x_new).  proj_pack / proj_bf from pack_proj, wpack / b1f / b2f from pack_mlp."""
+    _dev(x, "block_fused")
+    _dev(attn_out, "block_fused")
+    M, E = x.shape
+    if scratch is None:
+        scratch = torch.empty(int(load().mst_block_fused_scratch_bytes()), dtype=torch.uint8, device=x.device)
+    _check(load().mst_block_fused(ptr(x), ptr(attn_out), ptr(xn_out), dt_of(attn_out), ptr(proj_pack), ptr(proj_bf), ptr(wpack),
+                                  ptr(b1f), ptr(b2f), ptr(scratch), scratch.numel(), M, E, eps, stream_of(x)), "mst_block_fused")
+
+
+def _w2_row_order(dev):
+    R = torch.arange(384, device=dev)
+    t, i = R >> 4, R & 15
+    nphys = 32 * (t >> 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3)          # accumulator row R holds output column n(R)
+    cidx = torch.arange(4, device=dev)[None, :] ^ ((-(R >> 2)) & 3)[:, None]   # [R, slot] -> 16-byte chunk (bank swizzle)
+    return R, nphys, cidx
+
+
+def pack_proj(proj_w, proj_b, ls1, dtype: torch.dtype):
+    """Host-side packing of the attention out-projection for mst_block_fused (layout: include/mst_hip.h).  proj_w [384,384],
+    proj_b [384], ls1 [384] or None (LayerScale folded: layer_scale.py:26-27).  Returns (proj_pack [12, 12288] dtype,
+    proj_bf [384] fp32)."""
+    dev = proj_w.device
+    w = proj_w.float()
+    b = proj_b.float().clone()
+    if ls1 is not None:
+        w = w * ls1.float()[:, None]
+        b = b * ls1.float()
+    R, nphys, cidx = _w2_row_order(dev)
+    wc = w[nphys].view(384, 12, 4, 8).permute(1, 0, 2, 3)                   # [chunk, R, c, j]: natural k order inside a chunk
+    img = wc[:, R[:, None], cidx, :]                                        # [chunk, R, slot, 8]
+    return img.reshape(12, -1).to(dtype).contiguous(), b.contiguous()
 
 
 def pack_mlp(fc1_w, fc1_b, fc2_w, fc2_b, ln_w, ln_b, ls2, dtype: torch.dtype):

@@ -203,6 +203,56 @@ def test_mlp_fused(hip, dt, M, with_ls, with_xn):
         assert float((xn.double().cpu() - refn).abs().max()) < tol * 4
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,with_ls,with_xn,alias", [(16, False, True, False), (300, True, True, True), (128 * 300 + 5, False, False, False),
+                                                     (41000, True, True, True), (128 * 257, False, True, True)])
+def test_block_fused(hip, dt, M, with_ls, with_xn, alias):
+    """Out-projection + residual + LN2 -> fc1 -> GELU -> fc2 -> residual (+ next normalise) in ONE kernel (mst_block_fused)
+    vs an fp64 reference of the reference's block arithmetic (attention.py:67-68; block.py:89-94,112-113; mlp.py:34-40), and
+    against the two-launch path it replaces (mst_gemm residual epilogue + mst_mlp_fused).  `alias`: xn_out is the attention
+    output buffer itself, as the encoder calls it."""
+    tdt = DT[dt]
+    E, Hd = 384, 1536
+    x = rnd((M, E), 60, 1.5) + 0.3
+    att = (rnd((M, E), 61, 1.0)).to(tdt)
+    wp, bp = rnd((E, E), 62) / math.sqrt(E), rnd((E,), 63) * 0.1
+    w1, b1 = rnd((Hd, E), 51) / math.sqrt(E), rnd((Hd,), 52) * 0.1
+    w2, b2 = rnd((E, Hd), 53) / math.sqrt(Hd), rnd((E,), 54) * 0.1
+    g, be = rnd((E,), 55) * 0.2 + 1, rnd((E,), 56) * 0.2
+    ls1 = (rnd((E,), 64) * 0.3 + 1) if with_ls else None
+    ls2 = (rnd((E,), 57) * 0.3 + 1) if with_ls else None
+    cu = lambda v: None if v is None else v.cuda()
+    wpack, b1p, b2p = hip.pack_mlp(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), g.cuda(), be.cuda(), cu(ls2), tdt)
+    ppack, pbf = hip.pack_proj(wp.cuda(), bp.cuda(), cu(ls1), tdt)
+    xc = x.cuda().clone()
+    attc = att.cuda().clone()
+    xn = (attc if alias else torch.empty(M, E, dtype=tdt, device="cuda")) if with_xn else None
+    hip.block_fused(xc, attc, ppack, pbf, wpack, b1p, b2p, xn)
+    # fp64 reference on the same 16-bit attention output
+    xd = x.double()
+    proj = att.double() @ wp.double().t() + bp.double()
+    xmid = xd + (ls1.double() if ls1 is not None else 1.0) * proj
+    h = torch.nn.functional.layer_norm(xmid, (E,), g.double(), be.double(), 1e-6)
+    h = h @ w1.double().t() + b1.double()
+    h = 0.5 * h * (1 + torch.erf(h / math.sqrt(2)))
+    y = h @ w2.double().t() + b2.double()
+    ref = xmid + (ls2.double() if ls2 is not None else 1.0) * y
+    tol = {"bf16": 1.5e-2, "fp16": 2.5e-3}[dt]
+    scale = max(float(y.abs().max()), float(proj.abs().max()))
+    assert float((xc.double().cpu() - ref).abs().max() / scale) < tol
+    if with_xn:
+        refn = torch.nn.functional.layer_norm(ref, (E,))
+        assert float((xn.double().cpu() - refn).abs().max()) < tol * 4
+    # the two launches it replaces, on the same operands: same arithmetic up to the rounding of ls1-scaled weights
+    x2 = x.cuda().clone()
+    hip.gemm(att.cuda(), wp.cuda().to(tdt), bp.cuda(), epilogue=hip.EPI_RESIDUAL, out=x2, gamma=cu(ls1))
+    xn2 = torch.empty(M, E, dtype=tdt, device="cuda") if with_xn else None
+    hip.mlp_fused(x2, wpack, b1p, b2p, xn2, tdt)
+    assert float((xc - x2).abs().max() / scale) < tol
+    if not with_ls:
+        assert float((xc - x2).abs().max() / scale) < 2e-3     # identical weight rounding: only the summation order differs
+
+
 # ---------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, n, N, heads, hd):
     q, k, v = qkv.double().reshape(n, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
