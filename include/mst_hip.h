@@ -125,6 +125,11 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
                     const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
                     int E, float* x, mst_stream_t stream);
 
+/* slices2rgb (mst/models/dino.py:10-27; dead code in the reference: its call at dino.py:129 is commented out): three
+ * consecutive gray slices become the channels of one image.  vol [B,1,D,H,W] (dtype) -> out [B*Dp/3, 3, H, W] with
+ * Dp = D rounded up to a multiple of 3, the extra slices being the volume's own first Dp-D slices (needs Dp-D <= D). */
+int mst_slices2rgb(const void* vol, int dtype, int B, int D, int H, int W, void* out, mst_stream_t stream);
+
 /* Fused MLP half of a ViT block (block.py:93-94,113; mlp.py:34-40), E = 384, 16-bit operands:
  *   x[M,E] (fp32, in place) += ls2 * (fc2(gelu(fc1(normalise(x)))) + b2);  xn_out (nullable, dtype) = normalise(x_new)
  * with LayerScale ls2 folded by the caller into W2's rows and into b2f = ls2 * b2 (ls2 = 1 when absent).

@@ -170,6 +170,12 @@ int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const fl
     return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2f, M, E, eps, (hipStream_t)stream);
 }
 
+int mst_slices2rgb(const void* vol, int dtype, int B, int D, int H, int W, void* out, mst_stream_t stream) {
+    MST_CHECK_ARG(vol && out && B > 0 && D > 0 && H > 0 && W > 0, "slices2rgb: bad arguments");
+    MST_CHECK_ARG(dtype == MST_F32 || dtype == MST_F16 || dtype == MST_BF16, "slices2rgb: bad dtype %d", dtype);
+    return launch_slices2rgb(vol, dtype, B, D, H, W, out, (hipStream_t)stream);
+}
+
 size_t mst_block_fused_scratch_bytes(void) { return block16_scratch_bytes(); }
 
 int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, const void* proj_pack, const float* proj_bf,

@@ -206,6 +206,7 @@ int launch_saliency_accumulate(const float* maps, const float* slice_attn, int D
 int launch_saliency_upsample(const float* low, int D, int gh, int gw, float scale, int Dout, int H, int W, float* out,
                              hipStream_t s);
 int launch_bmm32_nn(const float* A, const float* B, float* C, int64_t batch, int M, int N, int K, hipStream_t s);
+int launch_slices2rgb(const void* vol, int dt, int B, int D, int H, int W, void* out, hipStream_t s);
 int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
 int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,
                    int R, int sheads, float* plane, float* slice_attn, float* maps, hipStream_t s);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_block_fused_scratch_bytes": (_sz, []),
     "mst_block_fused": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _f, _vp]),
+    "mst_slices2rgb": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
     "mst_vit_encode": (_i, [C.POINTER(VitWeights), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -257,6 +258,17 @@ def patch_embed(vol: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, prefix:
     _check(load().mst_patch_embed(ptr(vol), dt_of(vol), n, H, W, ptr(wp), dt_of(wp), ptr(bias), ptr(prefix), n_prefix,
                                   ptr(pos_patch), E, ptr(x), stream_of(vol)), "mst_patch_embed")
     return x
+
+
+def slices2rgb(vol: torch.Tensor) -> torch.Tensor:
+    """mst_slices2rgb: [B,1,D,H,W] -> [B*ceil(D/3), 3, H, W] (reference dino.py:10-27)."""
+    _dev(vol, "slices2rgb")
+    B, C, D, H, W = vol.shape
+    assert C == 1, "More than one channel"              # dino.py:14
+    Dp = (D + 2) // 3 * 3
+    out = torch.empty((B * Dp // 3, 3, H, W), dtype=vol.dtype, device=vol.device)
+    _check(load().mst_slices2rgb(ptr(vol), dt_of(vol), B, D, H, W, ptr(out), stream_of(vol)), "mst_slices2rgb")
+    return out
 
 
 def mlp_fused(x: torch.Tensor, wpack: torch.Tensor, b1f: torch.Tensor, b2f: torch.Tensor,

@@ -40,6 +40,13 @@ _VIT_SIZES = {  # reference: extern/dinov2/vision_transformer.py:340-395
 SLICE_HEADS = 12  # reference dino.py:87
 
 
+def slices2rgb(tensor):
+    """[B, 1, D, H, W] -> [B*ceil(D/3), 3, H, W]: three consecutive slices as the channels of one image, D padded with the
+    volume's own first slices (reference dino.py:10-27; dead code there -- its call at dino.py:129 is commented out --, kept
+    for the import surface).  Runs on the device (mst_slices2rgb)."""
+    return hip.slices2rgb(tensor.contiguous())
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter containers (names = the reference's state_dict keys)
 # ------------------------------------------------------------------------------------------------

@@ -397,6 +397,15 @@ def run_pred(sd: SD, source: Tensor, *, use_softmax: bool = True, use_tta: bool 
     return pred, trilinear_upsample(w, tuple(source.shape[2:])), ws
 
 
+def slices2rgb(tensor: Tensor) -> Tensor:
+    """dino.py:10-27: [B,1,D,H,W] -> [B*ceil(D/3), 3, H, W], padded along D with the first slices."""
+    B, C, D, H, W = tensor.shape
+    assert C == 1, "More than one channel"
+    if D % 3 != 0:
+        tensor = torch.cat([tensor, tensor[:, :, : 3 - D % 3]], dim=2)
+    return tensor.reshape(B, tensor.shape[2] // 3, 3, H, W).reshape(-1, 3, H, W)
+
+
 def flops_per_volume(D: int, H: int, W: int, E: int = 384, depth: int = 12) -> float:
     """Algorithmic FLOPs of one forward: 2 FLOP per MAC, softmax/LN/GELU not counted."""
     Np = (H // PATCH) * (W // PATCH)

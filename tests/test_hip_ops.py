@@ -469,3 +469,25 @@ def test_pos_embed_interp_antialias_matches_hub_register_fixture(hip):
         ref = F.interpolate(small, size=size, mode="bicubic", antialias=True)[0].permute(1, 2, 0).reshape(-1, 8)
         got = hip.pos_embed_interp(small[0].permute(1, 2, 0).reshape(25, 8).contiguous().cuda(), 5, size[0], size[1], 0.0, antialias=True)
         assert rel_l2(got.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 1, 7, 28, 28), (1, 1, 9, 14, 42), (3, 1, 5, 3, 5), (1, 1, 64, 518, 518)])
+def test_slices2rgb_matches_reference_arithmetic(hip, dt, shape):
+    """dino.py:10-27 (dead code in the reference; a16 of the scope table): bit-exact index shuffle, incl. the wrap-around padding."""
+    from mst.models.dino import slices2rgb
+    from oracle import mst_oracle as O
+    tdt = DT.get(dt, torch.float32)
+    x = rnd(shape, 77).to(tdt)
+    got = slices2rgb(x.cuda())
+    ref = O.slices2rgb(x)
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
+    with pytest.raises(AssertionError, match="More than one channel"):
+        slices2rgb(torch.zeros(1, 2, 3, 4, 4, device="cuda"))
+    if dt == "fp32" and shape[2] == 7:                   # what the reference's own function returned (tests/golden/slices2rgb.npz)
+        from conftest import load_golden
+        from mst import synth
+        g = load_golden("slices2rgb")
+        for i in range(3):
+            v = synth.synth_volume(tuple(int(u) for u in g[f"shape{i}"]), int(g[f"seed{i}"]))
+            assert np.array_equal(slices2rgb(v.cuda()).cpu().numpy(), g[f"out{i}"])

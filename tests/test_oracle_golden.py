@@ -208,3 +208,12 @@ def test_multichannel_input_matches_reference():
     assert np.abs(feat["features"].numpy() - g["features"]).max() < 5e-5
     assert rel_l2(O.slice_attention(out["slice_map"]), g["slice_attention"]) < 1e-4
     assert rel_l2(O.attention_maps(out["vit_maps"][-1], out["slice_map"]), g["attention_maps"]) < 1e-4
+
+
+def test_slices2rgb_restatement_matches_reference_fixture(golden):
+    """a16: the oracle's slices2rgb against what the reference's own function (dino.py:10-27) returned."""
+    from mst import synth
+    g = golden("slices2rgb")
+    for i in range(3):
+        x = synth.synth_volume(tuple(int(v) for v in g[f"shape{i}"]), int(g[f"seed{i}"]))
+        assert np.array_equal(O.slices2rgb(x).numpy(), g[f"out{i}"])

@@ -351,6 +351,18 @@ def case_hub_reg(synth, name, seed):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def case_slices2rgb(dino, synth):
+    """slices2rgb (reference dino.py:10-27) on seed-generated volumes: D % 3 = 1, 0 and 2."""
+    out = {}
+    for i, shape in enumerate([(2, 1, 7, 6, 10), (1, 1, 9, 4, 4), (3, 1, 5, 3, 5)]):
+        x = synth.synth_volume(shape, 300 + i)
+        out[f"shape{i}"] = np.array(shape)
+        out[f"seed{i}"] = np.array(300 + i)
+        out[f"out{i}"] = dino.slices2rgb(x).numpy()
+    np.savez_compressed(GOLD / "slices2rgb.npz", **out)
+    print("wrote slices2rgb.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -384,6 +396,7 @@ def main():
         "multichannel": lambda: case_multichannel(dino, synth, "multichannel", (2, 3, 2, 56, 70), 13),
         "hub_reg": lambda: case_hub_reg(synth, "hub_reg", 12),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
+        "slices2rgb": lambda: case_slices2rgb(dino, synth),
     }
     for name, fn in cases.items():
         if args.only and name not in args.only:
