@@ -157,6 +157,37 @@ int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, con
                     const void* wpack, const float* b1f, const float* b2f, void* scratch, size_t scratch_bytes, int64_t M,
                     int E, float eps, mst_stream_t stream);
 
+/* Training step: what torch.autograd does for the reference (base_model.py:148-181, main_train.py:110-126),
+ * as per-op entry points; mst/train.py orchestrates them behind a torch.autograd.Function.  All fp32, exact fp32 MFMA.
+ * mst_gemm_ex: C[b] = alpha * A[b] . B[b] + beta * C[b], A [M,K], B [K,N], C [M,N] with element strides
+ *   strides[12] = {A_m, A_k, B_k, B_n, C_m, C_n, A_b1, A_b2, B_b1, B_b2, C_b1, C_b2}, batch index b = b1 * nb2 + b2
+ *   (dX = dY.W, dW = dY^T.X of nn.Linear; S = q.k^T, O = P.v and the four backward products of attention.py:56-66 on the
+ *   packed q|k|v rows).  nb1 * nb2 <= 65535.
+ * mst_softmax_rows: S [rows, L] -> softmax over L in place; mask (nullable) uint8 [rows / rows_per_batch, L], 1 = key
+ *   ignored (src_key_padding_mask, transformer_blocks.py:244-252).  mst_softmax_rows_bwd: dP <- scale * P o (dP - rowsum(dP o P)).
+ * mst_layernorm_bwd: dx[r] = (dres ? dres[r] : 0) + LayerNorm'(x[r]; gamma) . dy[r]; dgamma[c] += sum_r dy xhat, dbeta[c] += sum_r dy
+ *   (dx, dres, dgamma, dbeta, gamma nullable; row strides in elements; cols <= 1024; accumulation by fp32 atomics).
+ * mst_act_fwd / mst_act_bwd: kind 0 GELU (erf form, mlp.py:22), 1 ReLU; bwd: dy <- dy * act'(h) in place.
+ * mst_colsum: out[c] += sum_r a[r][c] * (b ? b[r][c] : 1)   (bias and LayerScale gradients).
+ * mst_axpby_cols: y[r][c] = alpha * x[r][c] * (g ? g[c] : 1) + beta * y[r][c].
+ * mst_im2col14: vol [n,H,W] -> col fp32 [n*Np, 196], the 14 x 14 patches as rows (patch_embed.py:68-81; d W = dX^T . col).
+ * mst_pos_embed_interp_bwd: dpos [M*M, E] += adjoint of mst_pos_embed_interp (antialias = 0) applied to dout [gh*gw, E]. */
+int mst_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* strides, int nb1, int nb2,
+                float alpha, float beta, mst_stream_t stream);
+int mst_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_batch, mst_stream_t stream);
+int mst_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, float scale, mst_stream_t stream);
+int mst_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const float* dy, int64_t dy_stride, const float* dres,
+                      int64_t dres_stride, float* dx, int64_t dx_stride, float* dgamma, float* dbeta, int64_t rows, int cols,
+                      float eps, mst_stream_t stream);
+int mst_act_fwd(const float* h, float* y, int64_t n, int kind, mst_stream_t stream);
+int mst_act_bwd(const float* h, float* dy, int64_t n, int kind, mst_stream_t stream);
+int mst_colsum(const float* a, int64_t a_stride, const float* b, int64_t b_stride, int64_t rows, int cols, float* out,
+               mst_stream_t stream);
+int mst_axpby_cols(const float* x, int64_t x_stride, const float* g, float alpha, float beta, float* y, int64_t y_stride,
+                   int64_t rows, int cols, mst_stream_t stream);
+int mst_im2col14(const void* vol, int dtype, int n, int H, int W, float* col, mst_stream_t stream);
+int mst_pos_embed_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, mst_stream_t stream);
+
 /* Optional per-kernel timing of the launches inside mst_vit_encode (bench / profiling only).  A caller-owned object:
  * while mst_vit_weights.profiler points at one, every launch of that call is bracketed by hipEventRecord on the call's own
  * stream; mst_profiler_collect waits for the recorded events, returns the accumulated milliseconds and launch counts per

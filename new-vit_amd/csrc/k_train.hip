@@ -1,0 +1,348 @@
+// Kernels of the training step (the backward pass of DinoV2ClassifierSlice), all fp32 on the exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32): the first correct version -- gradients are checked against autograd of the CPU oracle at the
+// fp32 bar.  What the reference gets from torch.autograd (base_model.py:148-181 `_step`; main_train.py:110-126) is spelled out
+// here op by op:
+//   gemm_ex        C[b] = alpha * A[b] . B[b] (+ beta * C[b]), every operand with explicit element strides and a two-level batch:
+//                  one kernel covers dX = dY.W, dW = dY^T.X, and the four products of the attention backward on the packed
+//                  q|k|v layout of the forward (attention.py:56-66)
+//   softmax_rows / softmax_rows_bwd     P = softmax(S + key-padding mask),  dS = P o (dP - rowsum(dP o P))
+//   layernorm_bwd  dx (+ residual gradient), d gamma, d beta   (nn.LayerNorm; block.py:63,75; transformer_blocks.py:499)
+//   act_bwd        GELU (erf form, mlp.py:22) / ReLU (transformer_blocks.py:484) derivative times the upstream gradient
+//   colsum / colsum_prod / mul_cols     bias and LayerScale gradients (layer_scale.py:25-27)
+//   im2col14       the 14x14 patches of a gray volume as rows (patch_embed.py:68-81): d W_patch = dX^T . im2col
+//   pos_interp_bwd adjoint of the bicubic position-grid resampling (vision_transformer.py:179-211)
+#include "mst_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic strided, batched GEMM.  64 x 64 tile per 256-thread workgroup, four waves 2 x 2, K-step 16.
+struct GemmExArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, nb2;
+    int64_t sam, sak, sbk, sbn, scm, scn;          // element strides of A[m][k], B[k][n], C[m][n]
+    int64_t sa1, sa2, sb1, sb2, sc1, sc2;          // batch strides: batch index = b1 * nb2 + b2
+    float alpha, beta;
+};
+
+__global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
+    __shared__ float As[16][65], Bs[16][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
+    const float* A = g.A + b1 * g.sa1 + b2 * g.sa2;
+    const float* B = g.B + b1 * g.sb1 + b2 * g.sb2;
+    float* C = g.C + b1 * g.sc1 + b2 * g.sc2;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const bool a_kmajor = g.sak == 1, b_nmajor = g.sbn == 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;
+            const int am = a_kmajor ? idx >> 4 : idx & 63, ak = a_kmajor ? idx & 15 : idx >> 6;
+            const int bn = b_nmajor ? idx & 63 : idx >> 4, bk = b_nmajor ? idx >> 6 : idx & 15;
+            As[ak][am] = (m0 + am < g.M && k0 + ak < g.K) ? A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak] : 0.f;
+            Bs[bk][bn] = (n0 + bn < g.N && k0 + bk < g.K) ? B[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = 2 * kk + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][wr * 32 + (lane & 31)], Bs[k][wc * 32 + (lane & 31)], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + (lane & 31);
+    if (col >= g.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float* c = C + (int64_t)row * g.scm + (int64_t)col * g.scn;
+        *c = g.alpha * acc[r] + (g.beta != 0.f ? g.beta * *c : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// P = softmax over the last dim of S [B, H, Lq, L] (in place); mask uint8 [B, L], 1 = key ignored (-inf before the softmax).
+__global__ void softmax_rows_kernel(float* __restrict__ S, const uint8_t* __restrict__ mask, int64_t rows, int L, int rows_per_b) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* s = S + row * L;
+    const uint8_t* mk = mask ? mask + (row / rows_per_b) * L : nullptr;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, (mk && mk[j]) ? -INFINITY : s[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float e = (mk && mk[j]) ? 0.f : expf(s[j] - mx);
+        s[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < L; j += 64) s[j] *= inv;
+}
+
+// dS = scale * P o (dP - rowsum(dP o P)), written over dP.
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int64_t rows, int L, float scale) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = P + row * L;
+    float* d = dP + row * L;
+    float dot = 0.f;
+    for (int j = lane; j < L; j += 64) dot = fmaf(d[j], p[j], dot);
+    dot = wave_sum(dot);
+    for (int j = lane; j < L; j += 64) d[j] = scale * p[j] * (d[j] - dot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  One wave per row at a time, waves stride over the rows; d gamma / d beta partial sums live in registers
+// (column c = lane + 64 i, i < CI) and are added to the fp32 outputs with one atomic per column per wave.
+//   dx[row] = (dres ? dres[row] : 0) + rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),   dyg = dy * gamma
+template <int CI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, int64_t dys, const float* dres, int64_t drs,
+                                                            float* dx, int64_t dxs, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float gsum[CI], bsum[CI], gm[CI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+        gsum[i] = bsum[i] = 0.f;
+        const int c = lane + 64 * i;
+        gm[i] = (c < cols) ? (gamma ? gamma[c] : 1.f) : 0.f;
+    }
+    for (int64_t row = w; row < rows; row += nw) {
+        const float* xr = x + row * xs;
+        const float* dr = dy + row * dys;
+        float xv[CI], dv[CI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = c < cols ? xr[c] : 0.f;
+            dv[i] = c < cols ? dr[c] : 0.f;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) / (float)cols;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const float d = (lane + 64 * i < cols) ? xv[i] - mean : 0.f;
+            sq = fmaf(d, d, sq);
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)cols + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < CI; ++i) {
+            const bool in = lane + 64 * i < cols;
+            const float xh = in ? (xv[i] - mean) * rstd : 0.f;
+            const float dg = dv[i] * gm[i];
+            xv[i] = xh;
+            a += dg;
+            b = fmaf(dg, xh, b);
+            gsum[i] = fmaf(dv[i], xh, gsum[i]);
+            bsum[i] += dv[i];
+        }
+        a = wave_sum(a) / (float)cols;
+        b = wave_sum(b) / (float)cols;
+        if (dx) {
+#pragma unroll
+            for (int i = 0; i < CI; ++i) {
+                const int c = lane + 64 * i;
+                if (c < cols) {
+                    const float v = rstd * (dv[i] * gm[i] - a - xv[i] * b);
+                    dx[row * dxs + c] = (dres ? dres[row * drs + c] : 0.f) + v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) {
+            if (dgamma) atomicAdd(dgamma + c, gsum[i]);
+            if (dbeta) atomicAdd(dbeta + c, bsum[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dh = dy * act'(h), in place over dy.  kind 0: GELU (erf form), 1: ReLU.
+__global__ void act_bwd_kernel(const float* __restrict__ h, float* __restrict__ dy, int64_t n, int kind) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = h[i];
+        float d;
+        if (kind == 0) d = 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+        else d = v > 0.f ? 1.f : 0.f;
+        dy[i] *= d;
+    }
+}
+
+// y = act(h): the forward twin (the training forward keeps the pre-activation h for the backward).
+__global__ void act_fwd_kernel(const float* __restrict__ h, float* __restrict__ y, int64_t n, int kind) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = h[i];
+        y[i] = kind == 0 ? gelu_erf(v) : fmaxf(v, 0.f);
+    }
+}
+
+// out[j] += sum_i a[i][j] * (b ? b[i][j] : 1): thread per column, a block per chunk of rows.
+__global__ void colsum_kernel(const float* __restrict__ a, int64_t as, const float* __restrict__ b, int64_t bs, int64_t rows, int cols,
+                              int rows_per_block, float* __restrict__ out) {
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s = fmaf(a[r * as + c], b ? b[r * bs + c] : 1.f, s);
+        atomicAdd(out + c, s);
+    }
+}
+
+// y[i][j] = alpha * x[i][j] * (g ? g[j] : 1) + beta * y[i][j]   (LayerScale on a gradient; residual sums; plain scaling)
+__global__ void axpby_cols_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ g, float alpha, float beta,
+                                  float* __restrict__ y, int64_t ys, int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = alpha * x[r * xs + c] * (g ? g[c] : 1.f);
+        float* o = y + r * ys + c;
+        *o = v + (beta != 0.f ? beta * *o : 0.f);
+    }
+}
+
+// rows of 14 x 14 pixels: col[(n*Np + p)][ky*14 + kx] = vol[n][py*14 + ky][px*14 + kx]
+template <typename T>
+__global__ void im2col14_kernel(const T* __restrict__ vol, int H, int W, int gw, int Np, int64_t total, float* __restrict__ col) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / 196;
+        const int k = (int)(i - row * 196), ky = k / 14, kx = k - ky * 14;
+        const int64_t n = row / Np;
+        const int p = (int)(row - n * Np), py = p / gw, px = p - py * gw;
+        col[i] = to_f32(vol[(n * H + py * 14 + ky) * W + px * 14 + kx]);
+    }
+}
+
+__device__ __forceinline__ void cubic_w(float x, float w[4]) {   // F.interpolate bicubic, A = -0.75 (as k_patch.hip)
+    const float A = -0.75f;
+    float t = x + 1.0f;
+    w[0] = ((A * t - 5.0f * A) * t + 8.0f * A) * t - 4.0f * A;
+    w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    t = 1.0f - x;
+    w[2] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    t = 2.0f - x;
+    w[3] = ((A * t - 5.0f * A) * t + 8.0f * A) * t - 4.0f * A;
+}
+// adjoint of pos_interp_kernel: dpos[yy][xx][e] += wy[a] wx[b] dout[oy][ox][e]
+__global__ void pos_interp_bwd_kernel(const float* __restrict__ dout, int M, int E, int gh, int gw, float scale_y, float scale_x,
+                                      float* __restrict__ dpos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)gh * gw * E) return;
+    const int e = (int)(i % E);
+    const int ox = (int)((i / E) % gw);
+    const int oy = (int)(i / ((int64_t)E * gw));
+    const float ry = scale_y * ((float)oy + 0.5f) - 0.5f;
+    const float rx = scale_x * ((float)ox + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    float wy[4], wx[4];
+    cubic_w(ry - (float)iy, wy);
+    cubic_w(rx - (float)ix, wx);
+    const float d = dout[i];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), M - 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(ix - 1 + b, 0), M - 1);
+            atomicAdd(dpos + ((int64_t)yy * M + xx) * E + e, wy[a] * wx[b] * d);
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n, int block = 256, int cap = 16384) {
+    const int64_t gneed = (n + block - 1) / block;
+    return (unsigned)(gneed < 1 ? 1 : (gneed > cap ? cap : gneed));
+}
+
+}  // namespace
+
+int launch_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                   int64_t scm, int64_t scn, int nb1, int nb2, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1,
+                   int64_t sc2, float alpha, float beta, hipStream_t s) {
+    MST_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, "gemm_ex: bad arguments");
+    MST_CHECK_ARG((int64_t)nb1 * nb2 <= 65535, "gemm_ex: batch %d x %d exceeds the grid limit", nb1, nb2);
+    GemmExArgs g{A, B, C, M, N, K, nb2, sam, sak, sbk, sbn, scm, scn, sa1, sa2, sb1, sb2, sc1, sc2, alpha, beta};
+    gemm_ex_kernel<<<dim3((N + 63) / 64, (M + 63) / 64, nb1 * nb2), dim3(256), 0, s>>>(g);
+    return mst_check_launch("gemm_ex");
+}
+
+int launch_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_b, hipStream_t s) {
+    softmax_rows_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(S, mask, rows, L, rows_per_b);
+    return mst_check_launch("softmax_rows");
+}
+
+int launch_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, float scale, hipStream_t s) {
+    softmax_rows_bwd_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(P, dP, rows, L, scale);
+    return mst_check_launch("softmax_rows_bwd");
+}
+
+int launch_layernorm_bwd(const float* x, int64_t xs, const float* gamma, const float* dy, int64_t dys, const float* dres, int64_t drs,
+                         float* dx, int64_t dxs, float* dgamma, float* dbeta, int64_t rows, int cols, float eps, hipStream_t s) {
+    MST_CHECK_ARG(cols > 0 && cols <= 1024, "layernorm_bwd: cols=%d unsupported (<= 1024)", cols);
+    const unsigned grid = (unsigned)(rows < 4 ? 1 : (rows / 4 < 2048 ? rows / 4 : 2048));
+#define LNB(CI) layernorm_bwd_kernel<CI><<<dim3(grid), dim3(256), 0, s>>>(x, xs, gamma, dy, dys, dres, drs, dx, dxs, dgamma, dbeta, rows, cols, eps)
+    if (cols <= 128) LNB(2);
+    else if (cols <= 384) LNB(6);
+    else if (cols <= 768) LNB(12);
+    else LNB(16);
+#undef LNB
+    return mst_check_launch("layernorm_bwd");
+}
+
+int launch_act_bwd(const float* h, float* dy, int64_t n, int kind, hipStream_t s) {
+    act_bwd_kernel<<<dim3(grid_for(n)), dim3(256), 0, s>>>(h, dy, n, kind);
+    return mst_check_launch("act_bwd");
+}
+
+int launch_act_fwd(const float* h, float* y, int64_t n, int kind, hipStream_t s) {
+    act_fwd_kernel<<<dim3(grid_for(n)), dim3(256), 0, s>>>(h, y, n, kind);
+    return mst_check_launch("act_fwd");
+}
+
+int launch_colsum(const float* a, int64_t as, const float* b, int64_t bs, int64_t rows, int cols, float* out, hipStream_t s) {
+    const int rpb = 256;
+    colsum_kernel<<<dim3((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s>>>(a, as, b, bs, rows, cols, rpb, out);
+    return mst_check_launch("colsum");
+}
+
+int launch_axpby_cols(const float* x, int64_t xs, const float* g, float alpha, float beta, float* y, int64_t ys, int64_t rows,
+                      int cols, hipStream_t s) {
+    axpby_cols_kernel<<<dim3(grid_for(rows * cols)), dim3(256), 0, s>>>(x, xs, g, alpha, beta, y, ys, rows, cols);
+    return mst_check_launch("axpby_cols");
+}
+
+int launch_im2col14(const void* vol, int dt, int n, int H, int W, float* col, hipStream_t s) {
+    const int gw = W / 14, Np = (H / 14) * gw;
+    const int64_t total = (int64_t)n * Np * 196;
+    if (dt == MST_F32) im2col14_kernel<float><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const float*)vol, H, W, gw, Np, total, col);
+    else if (dt == MST_BF16) im2col14_kernel<bf16_t><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const bf16_t*)vol, H, W, gw, Np, total, col);
+    else if (dt == MST_F16) im2col14_kernel<f16_t><<<dim3(grid_for(total)), dim3(256), 0, s>>>((const f16_t*)vol, H, W, gw, Np, total, col);
+    else { mst_set_error("im2col14: bad dtype %d", dt); return MST_EINVAL; }
+    return mst_check_launch("im2col14");
+}
+
+int launch_pos_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, hipStream_t s) {
+    const float sy = (float)(1.0 / (((double)gh + offset) / (double)M));
+    const float sx = (float)(1.0 / (((double)gw + offset) / (double)M));
+    const int64_t tot = (int64_t)gh * gw * E;
+    pos_interp_bwd_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s>>>(dout, M, E, gh, gw, sy, sx, dpos);
+    return mst_check_launch("pos_interp_bwd");
+}

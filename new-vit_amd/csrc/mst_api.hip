@@ -170,6 +170,55 @@ int mst_mlp_fused(float* x, void* xn_out, int dtype, const void* wpack, const fl
     return launch_mlp16(x, xn_out, dtype, wpack, b1f, b2f, M, E, eps, (hipStream_t)stream);
 }
 
+// ---- training step: per-op entry points (the backward is orchestrated by mst/train.py) ---------------------------------
+int mst_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* st, int nb1, int nb2, float alpha,
+                float beta, mst_stream_t stream) {
+    MST_CHECK_ARG(st, "gemm_ex: null strides");
+    return launch_gemm_ex(A, B, C, M, N, K, st[0], st[1], st[2], st[3], st[4], st[5], nb1, nb2, st[6], st[7], st[8], st[9], st[10],
+                          st[11], alpha, beta, (hipStream_t)stream);
+}
+int mst_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_batch, mst_stream_t stream) {
+    MST_CHECK_ARG(S && rows > 0 && L > 0 && rows_per_batch > 0, "softmax_rows: bad arguments");
+    return launch_softmax_rows(S, mask, rows, L, rows_per_batch, (hipStream_t)stream);
+}
+int mst_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, float scale, mst_stream_t stream) {
+    MST_CHECK_ARG(P && dP && rows > 0 && L > 0, "softmax_rows_bwd: bad arguments");
+    return launch_softmax_rows_bwd(P, dP, rows, L, scale, (hipStream_t)stream);
+}
+int mst_layernorm_bwd(const float* x, int64_t x_stride, const float* gamma, const float* dy, int64_t dy_stride, const float* dres,
+                      int64_t dres_stride, float* dx, int64_t dx_stride, float* dgamma, float* dbeta, int64_t rows, int cols,
+                      float eps, mst_stream_t stream) {
+    MST_CHECK_ARG(x && dy && rows > 0, "layernorm_bwd: bad arguments");
+    return launch_layernorm_bwd(x, x_stride, gamma, dy, dy_stride, dres, dres_stride, dx, dx_stride, dgamma, dbeta, rows, cols, eps,
+                                (hipStream_t)stream);
+}
+int mst_act_fwd(const float* h, float* y, int64_t n, int kind, mst_stream_t stream) {
+    MST_CHECK_ARG(h && y && n > 0 && (kind == 0 || kind == 1), "act_fwd: bad arguments");
+    return launch_act_fwd(h, y, n, kind, (hipStream_t)stream);
+}
+int mst_act_bwd(const float* h, float* dy, int64_t n, int kind, mst_stream_t stream) {
+    MST_CHECK_ARG(h && dy && n > 0 && (kind == 0 || kind == 1), "act_bwd: bad arguments");
+    return launch_act_bwd(h, dy, n, kind, (hipStream_t)stream);
+}
+int mst_colsum(const float* a, int64_t a_stride, const float* b, int64_t b_stride, int64_t rows, int cols, float* out,
+               mst_stream_t stream) {
+    MST_CHECK_ARG(a && out && rows > 0 && cols > 0, "colsum: bad arguments");
+    return launch_colsum(a, a_stride, b, b_stride, rows, cols, out, (hipStream_t)stream);
+}
+int mst_axpby_cols(const float* x, int64_t x_stride, const float* g, float alpha, float beta, float* y, int64_t y_stride, int64_t rows,
+                   int cols, mst_stream_t stream) {
+    MST_CHECK_ARG(x && y && rows > 0 && cols > 0, "axpby_cols: bad arguments");
+    return launch_axpby_cols(x, x_stride, g, alpha, beta, y, y_stride, rows, cols, (hipStream_t)stream);
+}
+int mst_im2col14(const void* vol, int dtype, int n, int H, int W, float* col, mst_stream_t stream) {
+    MST_CHECK_ARG(vol && col && n > 0 && H > 0 && W > 0 && H % 14 == 0 && W % 14 == 0, "im2col14: bad arguments");
+    return launch_im2col14(vol, dtype, n, H, W, col, (hipStream_t)stream);
+}
+int mst_pos_embed_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, mst_stream_t stream) {
+    MST_CHECK_ARG(dout && dpos && M > 0 && E > 0 && gh > 0 && gw > 0, "pos_embed_interp_bwd: bad arguments");
+    return launch_pos_interp_bwd(dout, M, E, gh, gw, offset, dpos, (hipStream_t)stream);
+}
+
 int mst_slices2rgb(const void* vol, int dtype, int B, int D, int H, int W, void* out, mst_stream_t stream) {
     MST_CHECK_ARG(vol && out && B > 0 && D > 0 && H > 0 && W > 0, "slices2rgb: bad arguments");
     MST_CHECK_ARG(dtype == MST_F32 || dtype == MST_F16 || dtype == MST_BF16, "slices2rgb: bad dtype %d", dtype);

@@ -206,6 +206,21 @@ int launch_saliency_accumulate(const float* maps, const float* slice_attn, int D
 int launch_saliency_upsample(const float* low, int D, int gh, int gw, float scale, int Dout, int H, int W, float* out,
                              hipStream_t s);
 int launch_bmm32_nn(const float* A, const float* B, float* C, int64_t batch, int M, int N, int K, hipStream_t s);
+// training step (k_train.hip)
+int launch_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
+                   int64_t scm, int64_t scn, int nb1, int nb2, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1,
+                   int64_t sc2, float alpha, float beta, hipStream_t s);
+int launch_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_b, hipStream_t s);
+int launch_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, float scale, hipStream_t s);
+int launch_layernorm_bwd(const float* x, int64_t xs, const float* gamma, const float* dy, int64_t dys, const float* dres, int64_t drs,
+                         float* dx, int64_t dxs, float* dgamma, float* dbeta, int64_t rows, int cols, float eps, hipStream_t s);
+int launch_act_fwd(const float* h, float* y, int64_t n, int kind, hipStream_t s);
+int launch_act_bwd(const float* h, float* dy, int64_t n, int kind, hipStream_t s);
+int launch_colsum(const float* a, int64_t as, const float* b, int64_t bs, int64_t rows, int cols, float* out, hipStream_t s);
+int launch_axpby_cols(const float* x, int64_t xs, const float* g, float alpha, float beta, float* y, int64_t ys, int64_t rows,
+                      int cols, hipStream_t s);
+int launch_im2col14(const void* vol, int dt, int n, int H, int W, float* col, hipStream_t s);
+int launch_pos_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, hipStream_t s);
 int launch_slices2rgb(const void* vol, int dt, int B, int D, int H, int W, void* out, hipStream_t s);
 int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
 int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,

@@ -70,6 +70,16 @@ SIGNATURES = {
     "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_block_fused_scratch_bytes": (_sz, []),
     "mst_block_fused": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _f, _vp]),
+    "mst_gemm_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(_i64), _i, _i, _f, _f, _vp]),
+    "mst_softmax_rows": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "mst_softmax_rows_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "mst_layernorm_bwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _f, _vp]),
+    "mst_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "mst_act_bwd": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "mst_colsum": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _vp]),
+    "mst_axpby_cols": (_i, [_vp, _i64, _vp, _f, _f, _vp, _i64, _i64, _i, _vp]),
+    "mst_im2col14": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mst_pos_embed_interp_bwd": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
     "mst_slices2rgb": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),
@@ -433,6 +443,82 @@ def attention_rollout(maps: Sequence[torch.Tensor]) -> torch.Tensor:
     _check(load().mst_attention_rollout(arr, len(maps), batch, N, ptr(out), ptr(tmp), stream_of(m0)),
            "mst_attention_rollout")
     return out
+
+
+# ---- training-step ops (fp32; orchestrated by mst/train.py) ---------------------------------------------------------
+def gemm_ex(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, sa, sb, sc, nb=(1, 1),
+            ba=(0, 0), bb=(0, 0), bc=(0, 0), alpha: float = 1.0, beta: float = 0.0, offs=(0, 0, 0)):
+    """C[b] = alpha * A[b] . B[b] + beta * C[b]; sa = (A_m, A_k), sb = (B_k, B_n), sc = (C_m, C_n) element strides, nb = (nb1, nb2),
+    ba / bb / bc = per-level batch strides, offs = element offsets of A, B, C into their tensors (views without copies)."""
+    st = (_i64 * 12)(sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], ba[0], ba[1], bb[0], bb[1], bc[0], bc[1])
+    _check(load().mst_gemm_ex(A.data_ptr() + 4 * offs[0], B.data_ptr() + 4 * offs[1], C.data_ptr() + 4 * offs[2], M, N, K, st,
+                              nb[0], nb[1], alpha, beta, stream_of(C)), "mst_gemm_ex")
+    return C
+
+
+def softmax_rows(S: torch.Tensor, mask: Optional[torch.Tensor], rows_per_batch: int):
+    L = S.shape[-1]
+    _check(load().mst_softmax_rows(ptr(S), ptr(mask), S.numel() // L, L, rows_per_batch, stream_of(S)), "mst_softmax_rows")
+    return S
+
+
+def softmax_rows_bwd(P: torch.Tensor, dP: torch.Tensor, scale: float = 1.0):
+    L = P.shape[-1]
+    _check(load().mst_softmax_rows_bwd(ptr(P), ptr(dP), P.numel() // L, L, scale, stream_of(P)), "mst_softmax_rows_bwd")
+    return dP
+
+
+def layernorm_rows(x: torch.Tensor, x_stride: int, rows: int, cols: int, weight, bias, eps: float) -> torch.Tensor:
+    """LayerNorm of `rows` rows of `cols` fp32 values starting at x's first element, row stride x_stride -> [rows, cols] fp32."""
+    out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    _check(load().mst_layernorm(ptr(x), x_stride, ptr(weight), ptr(bias), ptr(out), F32, cols, rows, cols, eps, stream_of(x)),
+           "mst_layernorm")
+    return out
+
+
+def layernorm_bwd(x, x_stride, gamma, dy, dy_stride, dres, dres_stride, dx, dx_stride, dgamma, dbeta, rows, cols, eps):
+    _check(load().mst_layernorm_bwd(ptr(x), x_stride, ptr(gamma), ptr(dy), dy_stride, ptr(dres), dres_stride, ptr(dx), dx_stride,
+                                    ptr(dgamma), ptr(dbeta), rows, cols, eps, stream_of(x)), "mst_layernorm_bwd")
+
+
+def act_fwd(h: torch.Tensor, kind: int) -> torch.Tensor:
+    y = torch.empty_like(h)
+    _check(load().mst_act_fwd(ptr(h), ptr(y), h.numel(), kind, stream_of(h)), "mst_act_fwd")
+    return y
+
+
+def act_bwd(h: torch.Tensor, dy: torch.Tensor, kind: int) -> torch.Tensor:
+    _check(load().mst_act_bwd(ptr(h), ptr(dy), h.numel(), kind, stream_of(h)), "mst_act_bwd")
+    return dy
+
+
+def colsum(a: torch.Tensor, out: torch.Tensor, b: Optional[torch.Tensor] = None):
+    rows, cols = a.shape
+    _check(load().mst_colsum(ptr(a), cols, ptr(b), cols, rows, cols, ptr(out), stream_of(a)), "mst_colsum")
+    return out
+
+
+def axpby_cols(x: torch.Tensor, y: torch.Tensor, g: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 1.0,
+               rows: Optional[int] = None, cols: Optional[int] = None, x_stride: Optional[int] = None, y_stride: Optional[int] = None):
+    """y = alpha * x * g + beta * y over [rows, cols] (defaults: x's own 2-D shape, contiguous)."""
+    cols = cols if cols is not None else x.shape[-1]
+    rows = rows if rows is not None else x.numel() // cols
+    _check(load().mst_axpby_cols(ptr(x), x_stride if x_stride is not None else cols, ptr(g), alpha, beta, ptr(y),
+                                 y_stride if y_stride is not None else cols, rows, cols, stream_of(x)), "mst_axpby_cols")
+    return y
+
+
+def im2col14(vol: torch.Tensor) -> torch.Tensor:
+    n, H, W = vol.shape
+    col = torch.empty((n * (H // 14) * (W // 14), 196), dtype=torch.float32, device=vol.device)
+    _check(load().mst_im2col14(ptr(vol), dt_of(vol), n, H, W, ptr(col), stream_of(vol)), "mst_im2col14")
+    return col
+
+
+def pos_embed_interp_bwd(dout: torch.Tensor, M: int, gh: int, gw: int, offset: float, dpos: torch.Tensor):
+    E = dout.shape[-1]
+    _check(load().mst_pos_embed_interp_bwd(ptr(dout), M, E, gh, gw, offset, ptr(dpos), stream_of(dout)), "mst_pos_embed_interp_bwd")
+    return dpos
 
 
 class Profiler:

@@ -552,10 +552,14 @@ class DinoV2ClassifierSlice(BasicClassifier):
         return features, logits, probs
 
     def forward(self, source, save_attn=False, src_key_padding_mask=None, **kwargs):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and not self._warned_grad:
-            warnings.warn("DinoV2ClassifierSlice: the HIP path implements the forward only (the training step is a "
-                          "'next' row, SURVEY.md 8f-1); outputs carry no autograd graph.")
-            self._warned_grad = True
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training step (base_model.py:148-181): logits with ONE autograd node whose backward runs on the HIP kernels too
+            if save_attn:
+                raise NotImplementedError("save_attn inside a training forward: run the attention read-outs under torch.no_grad()")
+            if self._sharding is not None and self._sharding.world_size > 1:
+                raise NotImplementedError("training under slice sharding: use data-parallel ranks (DDP) for the training step")
+            from .. import train
+            return train.forward_with_grad(self, source, src_key_padding_mask, bool(kwargs.get("without_linear", False)))
         x = source.to(self.device)                      # [B, C, D, H, W]  (reference dino.py:121)
         B, C, D0, H, W = x.shape
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):

@@ -1,0 +1,126 @@
+"""the training step on the HIP path.  The gradient of EVERY parameter, produced by the kernels of
+csrc/k_train.hip behind one torch.autograd.Function, against torch.autograd through the CPU oracle (which the reference
+fixtures pin) on the same seeded weights and inputs: what the reference's `_step` (base_model.py:148-181) + autograd compute.
+Bar: max |dP_hip - dP_ref| <= 1e-3 * max |dP_ref| per parameter (fp32 path; fp32 atomics make the last bits run-dependent)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from mst import synth
+from test_model_gpu import CASES, build
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(name, kw, seed, src, mask, target, without_linear=False):
+    from oracle import mst_oracle as O
+    sd = synth.synth_state_dict(kw.get("model_size", "s"), seed, use_bottleneck=kw.get("use_bottleneck", False),
+                                use_slice_pos_emb=kw.get("use_slice_pos_emb", False),
+                                slice_fusion=kw.get("slice_fusion", "transformer"), rotary=kw.get("rotary_positional_encoding"))
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    out = O.forward(sd, src, model_size=kw.get("model_size", "s"), slice_fusion_type=kw.get("slice_fusion", "transformer"),
+                    src_key_padding_mask=mask, without_linear=without_linear)
+    y = out["features"] if without_linear else out["logits"]
+    loss = y.square().sum() if without_linear else torch.nn.functional.cross_entropy(y, target)
+    loss.backward()
+    return float(loss), {k: v.grad for k, v in sd.items()}, y.detach()
+
+
+def _check_all(model, ref_grads, rtol=1e-3):
+    worst = {}
+    for k, p in model.named_parameters():
+        r = ref_grads.get(k)
+        if r is None:                       # unused by the forward (mask_token): autograd leaves it without a gradient, so do we
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, f"no gradient for {k}"
+        g = p.grad.detach().cpu()
+        assert g.shape == r.shape, k
+        scale = float(r.abs().max())
+        err = float((g - r).abs().max())
+        worst[k] = err / max(scale, 1e-30)
+        assert err <= rtol * scale + 1e-9, (k, err, scale)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["c1_1x16x224", "b2_mask"])
+def test_every_parameter_gradient_matches_oracle_autograd(name):
+    g = load_golden(name)
+    kw = CASES[name]
+    model = build(kw, int(g["seed"]), "fp32").train()
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"]) if "src_key_padding_mask" in g else None
+    B = src.shape[0]
+    target = torch.arange(B) % 2
+    loss_ref, ref, y_ref = _oracle_grads(name, kw, int(g["seed"]), src, mask, target)
+    batch = {"source": src, "target": target.cuda(), "uid": ["x"] * B}
+    if mask is not None:
+        batch["src_key_padding_mask"] = mask
+    loss = model.training_step(batch, 0)                 # base_model.py:148-181: pred = self(**batch); CE loss
+    assert loss.requires_grad
+    assert abs(float(loss) - loss_ref) < 1e-4
+    loss.backward()
+    worst = _check_all(model, ref)
+    print(name, "worst relative gradient error:", max(worst.values()), max(worst, key=worst.get))
+    # the forward of the training path is the reference forward too
+    with torch.enable_grad():
+        logits = model(src, src_key_padding_mask=mask)
+    assert np.abs(logits.detach().cpu().numpy() - g["logits"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["bottleneck_pos", "average", "linear32"])
+def test_fusion_variants_gradients(name):
+    g = load_golden(name)
+    kw = CASES[name]
+    model = build(kw, int(g["seed"]), "fp32").train()
+    shape = tuple(int(v) for v in g["shape"])
+    src = synth.synth_volume(shape, int(g["seed"]) + 100)
+    target = torch.zeros(shape[0], dtype=torch.long)
+    _, ref, _ = _oracle_grads(name, kw, int(g["seed"]), src, None, target)
+    loss = torch.nn.functional.cross_entropy(model(src), target.cuda())
+    loss.backward()
+    _check_all(model, ref)
+
+
+def test_features_path_frozen_encoder_and_an_optimizer_step():
+    g = load_golden("b2_mask")
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    # without_linear: gradients of a function of the features
+    model = build({}, int(g["seed"]), "fp32").train()
+    _, ref, _ = _oracle_grads("b2_mask", {}, int(g["seed"]), src, mask, None, without_linear=True)
+    model(src, src_key_padding_mask=mask, without_linear=True).square().sum().backward()
+    ref = {k: v for k, v in ref.items() if not k.startswith("linear.")}
+    for k, p in model.named_parameters():
+        if k.startswith("linear."):
+            assert p.grad is None
+    _check_all(model, {**ref, "linear.weight": None, "linear.bias": None})
+    # freeze=True (dino.py:65-67): encoder parameters get no gradient, the rest is unchanged
+    from mst.models import DinoV2ClassifierSlice
+    fm = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp32", freeze=True)
+    fm.load_state_dict(synth.synth_state_dict("s", int(g["seed"])))
+    fm = fm.cuda().train()
+    target = torch.tensor([0, 1])
+    _, ref2, _ = _oracle_grads("b2_mask", {}, int(g["seed"]), src, mask, target)
+    torch.nn.functional.cross_entropy(fm(src, src_key_padding_mask=mask), target.cuda()).backward()
+    for k, p in fm.named_parameters():
+        if k.startswith("encoder."):
+            assert p.grad is None, k
+        else:
+            r = ref2[k]
+            assert float((p.grad.cpu() - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-9, k
+    # AdamW (dino.py:41) on the HIP gradients lowers the loss
+    model = build({}, int(g["seed"]), "fp32").train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(src, src_key_padding_mask=mask), target.cuda())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses
+    with torch.no_grad():                                # and the inference path sees the updated weights
+        model.eval()
+        assert torch.isfinite(model(src, src_key_padding_mask=mask)).all()
