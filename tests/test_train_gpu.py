@@ -124,3 +124,48 @@ def test_features_path_frozen_encoder_and_an_optimizer_step():
     with torch.no_grad():                                # and the inference path sees the updated weights
         model.eval()
         assert torch.isfinite(model(src, src_key_padding_mask=mask)).all()
+
+
+def _ddp_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share cuda:0 (RCCL refuses duplicate devices)
+    torch.cuda.set_device(0)
+    g = load_golden("b2_mask")
+    model = build({}, int(g["seed"]), "fp32").train()
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)   # [2, 1, 6, 112, 140]
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    target = torch.tensor([0, 1])
+    ddp = DDP(model, find_unused_parameters=True)                                                      # what Lightning's Trainer wraps the module in (main_train.py:110-126)
+    loss = torch.nn.functional.cross_entropy(ddp(src[rank:rank + 1], src_key_padding_mask=mask[rank:rank + 1]), target[rank:rank + 1].cuda())
+    loss.backward()                                                       # gradient all-reduce (mean over ranks) by DDP's bucket hooks
+    got = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    ret[rank] = got if rank == 0 else {k: None for k in got}
+    dist.destroy_process_group()
+
+
+def test_ddp_gradient_allreduce_two_ranks_one_gpu():
+    """Data-parallel training (BASELINE configs[3] style): every rank runs the HIP training step on its own volume, DDP averages the
+    gradients; the result must equal the single-process gradient of the mean loss over both volumes."""
+    import torch.multiprocessing as mp
+    g = load_golden("b2_mask")
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    target = torch.tensor([0, 1])
+    _, ref, _ = _oracle_grads("b2_mask", {}, int(g["seed"]), src, mask, target)      # CE over the batch = mean of the two per-volume losses
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, 29577, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = ret[0]
+    for k, r in ref.items():
+        if r is None:
+            continue
+        assert k in got, k
+        assert float((got[k] - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-9, k
