@@ -41,14 +41,24 @@ constexpr int HBUF = 2 * NSLOT * W1_BYTES;              // byte offset of the H 
 constexpr int LDS_BYTES = HBUF + 2 * 8192;              // 163,840 = all of the LDS
 constexpr int KS = E / 32;                              // 12 k-steps of GEMM1
 constexpr int NT = E / 16;                              // 24 output tiles (16 columns) of GEMM2 / the out-projection
-constexpr int DEPTH = 4;                                // fragment reads in flight ahead of the MFMAs
+#ifndef BLOCK_DEPTH_P
+#define BLOCK_DEPTH_P 4
+#endif
+#ifndef BLOCK_DEPTH_C
+#define BLOCK_DEPTH_C 4
+#endif
+constexpr int DEPTH_P = BLOCK_DEPTH_P, DEPTH_C = BLOCK_DEPTH_C;   // fragment reads in flight ahead of the MFMAs (producer / consumer loop)
 constexpr int SCRATCH_WG = 4 * 2 * KS * 1024;           // 96 KiB of normalised rows per workgroup
 #ifndef BLOCK_TILE_CYCLES
 #define BLOCK_TILE_CYCLES 190000                        // ~one 128-row tile (62 steps) in shader clocks: the de-phasing window
 #endif
 
 template <int OFF, typename V> __device__ __forceinline__ void lds_read_b128(V& dst, unsigned addr) {
+#ifndef ABL_NO_READS
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+#else
+    asm volatile("" : "=v"(dst) : "v"(addr));            // timing-only ablation: fragments are whatever the registers hold
+#endif
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() {       // + fence: no MFMA above the wait (rule 18)
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
@@ -60,6 +70,13 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
         static_for<I + 1, N>(f);
     }
 }
+template <typename T> __device__ __forceinline__ float gelu_blk(float v) {
+#ifdef ABL_NO_GELU
+    return v;                                            // timing-only ablation
+#else
+    return gelu_sig<T>(v);
+#endif
+}
 // LDS-DMA pieces per wave in the group that lands for local step t (issued two steps earlier)
 __device__ __forceinline__ int group_size(int t) {
     return t < PJ ? 8 : (t < J_G2 ? 6 : (t < J_G1 + NCHUNK ? 12 : 6));
@@ -70,6 +87,23 @@ __device__ __forceinline__ void wait_vm(int n) {        // n wave-uniform: all b
     else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+#ifdef BLOCK_STAMPS
+// diagnostic build only (never shipped): per-wave cycle sums by phase, read back by mst_debug_block_stamps
+__device__ unsigned long long g_bstamps[256 * 8 * 8];
+__device__ __forceinline__ unsigned long long bstamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define BST(var) const unsigned long long var = bstamp()
+#define BACC(slot, a, b) st[slot] += (b) - (a)
+#else
+#define BST(var)
+#define BACC(slot, a, b)
+#endif
 
 #ifdef BLOCK_DEBUG
 // diagnostic build only (never shipped): what each role saw of the LayerNorm2 hand-off, [wg][role][pr][i][lane] x 16 B
@@ -110,6 +144,9 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
     // Consumers issue it two steps ahead.  Piece u of wave pr is image piece 4u + pr (1 KiB each).
     char* const ring_wave = smem + pr * 1024;
     auto dma_w = [&](const char* src, char* dst) {       // a 24 KiB image (src wave-uniform): this wave's 6 pieces
+#ifdef BLOCK_NODMA
+        return;                                          // timing-only ablation: weights are whatever the LDS holds
+#endif
 #pragma unroll
         for (int u = 0; u < 6; ++u)
             __builtin_amdgcn_global_load_lds(GLB_PTR((src + u * 4096) + lane16), LDS_PTR(dst + u * 4096), 16, 0, 0);
@@ -153,6 +190,13 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
     }
 
     const int nsteps = my_tiles * P;
+#ifdef BLOCK_CONS_PRIO
+    // static priority for the consumer half (waves 4-7: the younger half, loser of the VALU arbitration, and the critical path)
+    if (!producer) __builtin_amdgcn_s_setprio(BLOCK_CONS_PRIO);
+#endif
+#ifdef BLOCK_PROD_PRIO
+    if (producer) __builtin_amdgcn_s_setprio(BLOCK_PROD_PRIO);
+#endif
 #define ACC(t, mt) R[2 * (t) + (mt)]
 #define XA(mt, ks) R[KS * (mt) + (ks)]
     if (producer) {
@@ -170,10 +214,28 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 *reinterpret_cast<vec8*>(hslot + mt * 1024 + (c & 1) * 8192) = hv;
             }
         };
-        int j = 0, slot = 0;
+        int j = 0, k = 0, slot = 0;
+#ifdef BLOCK_WARM
+        float warm[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
+#ifdef BLOCK_STAMPS
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long tstart = bstamp();
+#endif
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
+            BST(p0);
+#ifdef BLOCK_WARM
+            // GEMM1 steps: own loads (bias, normalised rows) and the H(s-2) writes are drained before the barrier.  In the idle
+            // steps nothing of this wave's vector memory matters to anyone, and the pre-touch loads below must NOT be waited for.
+            if (j >= J_G1 && j <= J_G1 + NCHUNK) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (j == J_G1) asm volatile("" ::"v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]), "v"(warm[4]), "v"(warm[5]), "v"(warm[6]), "v"(warm[7]), "v"(warm[8]));
+#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // own loads / H(s-2) writes drained
+#endif
+            BST(p1);
+            if (j > J_G1 && j <= J_G1 + NCHUNK) BACC(0, p0, p1); else BACC(2, p0, p1);
             if (j == J_G1) {
                 // normalised rows of this tile from the consumer twin wave: written by the same lanes with plain stores that were
                 // drained (vmcnt(0)) before this barrier; same CU, same L1: workgroup-scope visibility needs nothing more
@@ -198,23 +260,58 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                     bias_next[1] = *reinterpret_cast<const f32x4*>(b1f + cn * CH + 16 + 4 * g);
                 }
                 f32x4 h[2][2] = {{b0, b0}, {b1v, b1v}};  // [hidden tile][row tile]
-                float gv[16];                            // GELU of the PREVIOUS chunk, interleaved with this chunk's MFMAs
+#ifdef BLOCK_GELU_FIRST
+                // GELU + hand-off of the PREVIOUS chunk FIRST: its vector work (16 exp2 + 16 rcp + ~60 plain ops per lane) runs while
+                // the consumer twin on this SIMD has the matrix pipe to itself for its 48 MFMAs; this wave's own 48 MFMAs follow
+                // when the pipe is free again.  (hipcc otherwise sinks the GELU below the MFMA loop -- both waves then share the
+                // pipe first and the GELU runs alone afterwards: 2,650 instead of ~1,700 cycles per step.)
+                if (c != 0) {
+                    float gv0[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) gv0[e] = gelu_blk<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                    store_h(gv0, c - 1);                 // H(c-1)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                float gv[16];                            // (BLOCK_GELU_LAST: GELU of the previous chunk after this chunk's MFMAs)
                 const unsigned w1a = lds_base + slot * W1_BYTES + frag_off;
                 vec8 w[2 * KS];                          // fragment index q = 2*ks + ht  ->  byte offset ks*2048 + ht*1024
                 wait_lgkm<0>();
-                static_for<0, DEPTH>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<(q >> 1) * 2048 + (q & 1) * 1024>(w[q], w1a); });
+                static_for<0, DEPTH_P>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<(q >> 1) * 2048 + (q & 1) * 1024>(w[q], w1a); });
                 static_for<0, 2 * KS>([&](auto i) {
                     constexpr int q = decltype(i)::value;
-                    if constexpr (q + DEPTH < 2 * KS) lds_read_b128<((q + DEPTH) >> 1) * 2048 + ((q + DEPTH) & 1) * 1024>(w[q + DEPTH], w1a);
-                    wait_lgkm<(2 * KS - 1 - q < DEPTH) ? (2 * KS - 1 - q) : DEPTH>();
+                    if constexpr (q + DEPTH_P < 2 * KS) lds_read_b128<((q + DEPTH_P) >> 1) * 2048 + ((q + DEPTH_P) & 1) * 1024>(w[q + DEPTH_P], w1a);
+                    wait_lgkm<(2 * KS - 1 - q < DEPTH_P) ? (2 * KS - 1 - q) : DEPTH_P>();
+#ifndef ABL_NO_MFMA_P
                     h[q & 1][0] = mfma16(w[q], __builtin_bit_cast(vec8, XA(0, q >> 1)), h[q & 1][0]);
                     h[q & 1][1] = mfma16(w[q], __builtin_bit_cast(vec8, XA(1, q >> 1)), h[q & 1][1]);
-                    if constexpr (q % 3 != 2) {          // 16 of the 24 iterations carry one GELU each (VALU under the MFMAs)
+#else
+                    asm volatile("" ::"v"(w[q]));
+#endif
+#ifndef BLOCK_GELU_FIRST
+#if !defined(BLOCK_GELU_GROUP) || BLOCK_GELU_GROUP == 0
+                    // (hipcc sinks these below the whole MFMA loop: the values are not needed before store_h)
+                    if constexpr (q % 3 != 2) {
                         constexpr int e = q - q / 3;
-                        gv[e] = gelu_sig<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                        gv[e] = gelu_blk<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
                     }
+#else
+                    // GELU of the previous chunk really interleaved with this chunk's MFMAs: GG values per carrying iteration,
+                    // pinned there by an empty asm (independent chains of one iteration hide each other's latency)
+                    constexpr int GG = BLOCK_GELU_GROUP, EVERY = 24 / (16 / GG);
+                    if constexpr (GG == 1 ? (q % 3 != 2) : (q % EVERY == 0)) {
+                        constexpr int e0 = GG == 1 ? q - q / 3 : GG * (q / EVERY);
+#pragma unroll
+                        for (int u = 0; u < GG; ++u) gv[e0 + u] = gelu_blk<T>(hp[((e0 + u) >> 2) & 1][(e0 + u) >> 3][(e0 + u) & 3]);
+#pragma unroll
+                        for (int u = 0; u < GG; ++u) asm volatile("" : "+v"(gv[e0 + u]));
+                    }
+#endif
+#endif
                 });
+#ifndef BLOCK_GELU_FIRST
                 if (c != 0) store_h(gv, c - 1);          // H(c-1)
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -222,12 +319,47 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
             } else if (j == J_G1 + NCHUNK) {             // drain: GELU + hand-off of the last chunk
                 float gv[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) gv[e] = gelu_sig<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
+                for (int e = 0; e < 16; ++e) gv[e] = gelu_blk<T>(hp[(e >> 2) & 1][e >> 3][e & 3]);
                 store_h(gv, NCHUNK - 1);
+#ifdef BLOCK_WARM
+                if (k + 1 < my_tiles) {
+                    // The NEXT tile's residual rows (196 KB) and attention-output rows (96 KB) are pulled towards the L2 now: the
+                    // consumers read the former at their step 0 in one burst and the latter by LDS-DMA only two (short) steps
+                    // ahead of each out-projection step -- cold, both are HBM round trips on the critical path (stamps: 3,900
+                    // cycles per out-projection step, 17,700 for the x rows).  One dword per 128-byte line, 9 per lane, results
+                    // consumed (= waited for) only at step J_G1 of the next tile.
+                    const int tile = blockIdx.x + (k + 1) * gridDim.x;
+                    const int rows = M - tile * 128 < 128 ? M - tile * 128 : 128;
+                    const char* const xb = (const char*)(x + (size_t)tile * 128 * E);
+                    const char* const ab = (const char*)(attn + (size_t)tile * 128 * E);
+                    unsigned l = (unsigned)(pr * 64 + lane);
+                    asm volatile("" : "+v"(l));
+                    const unsigned xl = (unsigned)rows * 12u, al = (unsigned)rows * 6u;     // 128-byte lines of the two row sets
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const unsigned li = l + q * 256;
+                        warm[q] = *reinterpret_cast<const float*>(xb + (size_t)(li < xl ? li : xl - 1) * 128);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const unsigned li = l + q * 256;
+                        warm[6 + q] = *reinterpret_cast<const float*>(ab + (size_t)(li < al ? li : al - 1) * 128);
+                    }
+                }
+#endif
             }
-            if (++j == P) j = 0;
+            BST(p2);
+            if (j > J_G1 && j <= J_G1 + NCHUNK) BACC(1, p1, p2); else if (j == J_G1) BACC(3, p1, p2);
+            if (++j == P) { j = 0; ++k; }
             if (++slot == NSLOT) slot = 0;
         }
+#ifdef BLOCK_WARM
+        asm volatile("" ::"v"(warm[0]), "v"(warm[1]), "v"(warm[2]), "v"(warm[3]), "v"(warm[4]), "v"(warm[5]), "v"(warm[6]), "v"(warm[7]), "v"(warm[8]));
+#endif
+#ifdef BLOCK_STAMPS
+        st[7] = bstamp() - tstart;
+        if (lane == 0) for (int i = 0; i < 8; ++i) g_bstamps[(blockIdx.x * 8 + wave) * 8 + i] = st[i];
+#endif
     } else {
         u32x4 R[2 * NT];                                 // acc[t][mt]: y^T accumulators (x rides inside)
         auto load_x = [&](int tile) {                    // all 48 row pieces in flight at once (one HBM round trip)
@@ -316,8 +448,14 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
             }
         };
         int j = 0, k = 0, slot = 0;
+#ifdef BLOCK_STAMPS
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long tstart = bstamp();
+#endif
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
+            BST(c0);
+            int jt_late = 0, kt_late = 0, st_late = 0;
             // this wave's pieces of the group for THIS step have landed; the group for the next step may stay in flight.
             // Step J_G1 is different: the normalised rows stored at the end of step J_G1-1 must have left before the barrier.
             {
@@ -326,20 +464,28 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 wait_vm((j == J_G1 || kn >= my_tiles) ? 0 : group_size(jn));
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            BST(c1);
+            if (j >= J_G2 && j < P - 1) BACC(0, c0, c1);
             {
                 int jt = j + 2, kt = k;
                 if (jt >= P) { jt -= P; ++kt; }
-                int st = slot + 2;
-                if (st >= NSLOT) st -= NSLOT;
-                dma_group(jt, kt, st);
+                int sl = slot + 2;
+                if (sl >= NSLOT) sl -= NSLOT;
+#ifndef BLOCK_DMA_LATE
+                dma_group(jt, kt, sl);
+#else
+                jt_late = jt; kt_late = kt; st_late = sl;
+#endif
             }
             const int tile = blockIdx.x + k * gridDim.x;
+            BST(c2);
             if (j == 0) {
                 // new tile: accumulators start at x + ls1*b_proj (the residual rides in the accumulators: x is read once).
-                // Tiles after the first had their rows requested at the end of the previous tile's last step.
                 load_x(tile);
                 add_bias(bproj);
             }
+            BST(c3);
+            if (j == 0) BACC(3, c2, c3);
             if (j < PJ || j >= J_G2) {
                 // ---- one 32-deep chunk: y^T[384 x 32 rows] += Wc[384 x 32] . B^T, B = attention output columns (from the W1 ring)
                 // or H of MLP chunk j - J_G2 (from the hand-off slot)
@@ -349,15 +495,26 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 lds_read_b128<1024>(hf1, hb);
                 const unsigned w2a = lds_base + W2_RING + slot * W2_BYTES + frag_off;
                 vec8 w[NT];
-                static_for<0, DEPTH>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<q * 1024>(w[q], w2a); });
+                static_for<0, DEPTH_C>([&](auto i) { constexpr int q = decltype(i)::value; lds_read_b128<q * 1024>(w[q], w2a); });
                 static_for<0, NT>([&](auto i) {
                     constexpr int q = decltype(i)::value;
-                    if constexpr (q + DEPTH < NT) lds_read_b128<(q + DEPTH) * 1024>(w[q + DEPTH], w2a);
-                    wait_lgkm<(NT - 1 - q < DEPTH) ? (NT - 1 - q) : DEPTH>();
+                    if constexpr (q + DEPTH_C < NT) lds_read_b128<(q + DEPTH_C) * 1024>(w[q + DEPTH_C], w2a);
+                    wait_lgkm<(NT - 1 - q < DEPTH_C) ? (NT - 1 - q) : DEPTH_C>();
+#ifndef ABL_NO_MFMA_C
                     ACC(q, 0) = __builtin_bit_cast(u32x4, mfma16(w[q], hf0, __builtin_bit_cast(f32x4, ACC(q, 0))));
                     ACC(q, 1) = __builtin_bit_cast(u32x4, mfma16(w[q], hf1, __builtin_bit_cast(f32x4, ACC(q, 1))));
+#else
+                    asm volatile("" ::"v"(w[q]), "v"(hf0), "v"(hf1));
+#endif
                 });
             }
+#ifdef BLOCK_DMA_LATE
+            dma_group(jt_late, kt_late, st_late);        // issue AFTER this step's MFMAs (it lands for step + 2 either way)
+#endif
+            BST(c4);
+            if (j >= J_G2 && j < P - 1) BACC(1, c1, c4);
+            else if (j < PJ) BACC(2, c0, c4);
+            else if (j < J_G2) BACC(6, c0, c4);
             if (j == PJ - 1) {
                 // the accumulators hold x_mid (after the out-projection): LayerNorm2 for the producer twin, then + ls2*b2
                 rows_done(std::false_type{}, tile);
@@ -366,9 +523,16 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 // the block's output rows: x, the next block's normalised rows; then request the next tile's rows
                 rows_done(std::true_type{}, tile);
             }
+            BST(c5);
+            if (j == PJ - 1) BACC(4, c4, c5);
+            else if (j == P - 1) { BACC(5, c4, c5); BACC(5, c0, c4); }
             if (++j == P) { j = 0; ++k; }
             if (++slot == NSLOT) slot = 0;
         }
+#ifdef BLOCK_STAMPS
+        st[7] = bstamp() - tstart;
+        if (lane == 0) for (int i = 0; i < 8; ++i) g_bstamps[(blockIdx.x * 8 + wave) * 8 + i] = st[i];
+#endif
     }
 }
 
@@ -387,6 +551,12 @@ int launch_t(float* x, const void* attn, void* xn_out, const void* wproj, const 
 }
 
 }  // namespace
+
+#ifdef BLOCK_STAMPS
+extern "C" int mst_debug_block_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 #ifdef BLOCK_DEBUG
 extern "C" int mst_debug_block_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_block_dbg), &p, sizeof(p)); }

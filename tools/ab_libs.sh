@@ -1,0 +1,9 @@
+#!/bin/bash
+# Run tools/bench_block.py once per library variant (same box, back to back; two rounds to see the run-to-run spread).
+mkdir -p gpurun_out
+for round in 1 2; do
+  for lib in new-vit_amd/mst/hip/libmst_hip.so new-vit_amd/mst/hip/libv_*.so; do
+    echo "== round $round $lib"
+    MST_HIP_LIB=$PWD/$lib timeout -k 5 120 python tools/bench_block.py 2>/dev/null | grep "^new"
+  done
+done
