@@ -125,6 +125,22 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
                     const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
                     int E, float* x, mst_stream_t stream);
 
+/* Input pipeline in front of the model (reference mst/data/datasets/augmentations/augmentations_3d.py on
+ * torchio 0.19.9, which is not part of the reference tree: restated from its published algorithm, numpy.pad semantics included).
+ * mst_crop_or_pad: CropOrPad (l.144-195) with the deterministic centre (random_center=False: ini = ceil(n/2), fin = n - ini per
+ *   axis).  src fp32 [s0,s1,s2] -> dst fp32 [t0,t1,t2]; padding first (pad_minimum = 1: numpy.pad mode 'minimum', axis after
+ *   axis, what the datasets use; 0: the constant pad_value), then cropping.  ws: (s0+p0)(s1+p1)(s2+p2) floats when an axis is
+ *   padded while another is cropped, else unused.
+ * mst_znorm: ZNormalization (l.40-86) of ONE channel (per_channel=True, per_slice=False) with the datasets' masking method
+ *   (x > x.min()) & (x < x.max()): cut-offs = torch.quantile(masked values, {q_lo, q_hi}) (linear), clamp, then
+ *   y = (clamp(x) - mean) / std with mean / unbiased std of the masked clamped values.  Everything stays on the device (exact
+ *   order statistics by radix select); `state` (mst_znorm_state_bytes()) receives, among others, a zero_std flag the host mirror
+ *   turns into the reference's RuntimeError. */
+int mst_crop_or_pad(const float* src, int s0, int s1, int s2, float* dst, int t0, int t1, int t2, int pad_minimum,
+                    float pad_value, void* ws, size_t ws_bytes, mst_stream_t stream);
+size_t mst_znorm_state_bytes(void);
+int mst_znorm(const float* x, int64_t n, float q_lo, float q_hi, float* y, void* state, mst_stream_t stream);
+
 /* slices2rgb (mst/models/dino.py:10-27; dead code in the reference: its call at dino.py:129 is commented out): three
  * consecutive gray slices become the channels of one image.  vol [B,1,D,H,W] (dtype) -> out [B*Dp/3, 3, H, W] with
  * Dp = D rounded up to a multiple of 3, the extra slices being the volume's own first Dp-D slices (needs Dp-D <= D). */

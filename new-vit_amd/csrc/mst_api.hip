@@ -219,6 +219,46 @@ int mst_pos_embed_interp_bwd(const float* dout, int M, int E, int gh, int gw, do
     return launch_pos_interp_bwd(dout, M, E, gh, gw, offset, dpos, (hipStream_t)stream);
 }
 
+// ---- input pipeline ------------------------------------------------------------------------------------
+int mst_crop_or_pad(const float* src, int s0, int s1, int s2, float* dst, int t0, int t1, int t2, int pad_minimum,
+                    float pad_value, void* ws, size_t ws_bytes, mst_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MST_CHECK_ARG(src && dst && s0 > 0 && s1 > 0 && s2 > 0 && t0 > 0 && t1 > 0 && t2 > 0, "crop_or_pad: bad arguments");
+    const int sn[3] = {s0, s1, s2}, tn[3] = {t0, t1, t2};
+    int pad_lo[3], pad_hi[3], crop_lo[3], pn[3];
+    bool any_pad = false;
+    for (int a = 0; a < 3; ++a) {                       // augmentations_3d.py:164-172: ini = ceil(n / 2), fin = n - ini
+        const int d = tn[a] - sn[a];
+        const int p = d > 0 ? d : 0, c = d < 0 ? -d : 0;
+        pad_lo[a] = (p + 1) / 2; pad_hi[a] = p - pad_lo[a];
+        crop_lo[a] = (c + 1) / 2;
+        pn[a] = sn[a] + p;
+        any_pad = any_pad || p > 0;
+    }
+    if (!any_pad)                                        // crop only
+        return launch_copy_block(src, s1, s2, crop_lo[0], crop_lo[1], crop_lo[2], dst, t1, t2, 0, 0, 0, t0, t1, t2, s);
+    const bool direct = pn[0] == t0 && pn[1] == t1 && pn[2] == t2;    // pad only: build the padded array in dst itself
+    const size_t need = direct ? 0 : sizeof(float) * (size_t)pn[0] * pn[1] * pn[2];
+    MST_CHECK_ARG(direct || (ws && ws_bytes >= need), "crop_or_pad: workspace %zu < %zu bytes", ws_bytes, need);
+    float* pad = direct ? dst : (float*)ws;
+    int rc = launch_copy_block(src, s1, s2, 0, 0, 0, pad, pn[1], pn[2], pad_lo[0], pad_lo[1], pad_lo[2], s0, s1, s2, s);
+    if (rc) return rc;
+    // numpy.pad: one axis after the other; axis a sees the pads of the axes before it and only the valid part of the later ones
+    const int lo0 = pad_lo[0], hi0 = pad_lo[0] + s0, lo1 = pad_lo[1], hi1 = pad_lo[1] + s1, lo2 = pad_lo[2], hi2 = pad_lo[2] + s2;
+    if (pn[0] > s0 && (rc = launch_pad_axis(pad, pn[0], pn[1], pn[2], 0, lo0, hi0, lo1, hi1, lo2, hi2, !pad_minimum, pad_value, s))) return rc;
+    if (pn[1] > s1 && (rc = launch_pad_axis(pad, pn[0], pn[1], pn[2], 1, lo1, hi1, 0, pn[0], lo2, hi2, !pad_minimum, pad_value, s))) return rc;
+    if (pn[2] > s2 && (rc = launch_pad_axis(pad, pn[0], pn[1], pn[2], 2, lo2, hi2, 0, pn[0], 0, pn[1], !pad_minimum, pad_value, s))) return rc;
+    if (direct) return MST_OK;
+    return launch_copy_block(pad, pn[1], pn[2], crop_lo[0], crop_lo[1], crop_lo[2], dst, t1, t2, 0, 0, 0, t0, t1, t2, s);
+}
+
+size_t mst_znorm_state_bytes(void) { return znorm_state_bytes(); }
+
+int mst_znorm(const float* x, int64_t n, float q_lo, float q_hi, float* y, void* state, mst_stream_t stream) {
+    MST_CHECK_ARG(x && y && state && n > 0 && q_lo >= 0.f && q_lo <= q_hi && q_hi <= 1.f, "znorm: bad arguments");
+    return launch_znorm(x, n, q_lo, q_hi, y, state, (hipStream_t)stream);
+}
+
 int mst_slices2rgb(const void* vol, int dtype, int B, int D, int H, int W, void* out, mst_stream_t stream) {
     MST_CHECK_ARG(vol && out && B > 0 && D > 0 && H > 0 && W > 0, "slices2rgb: bad arguments");
     MST_CHECK_ARG(dtype == MST_F32 || dtype == MST_F16 || dtype == MST_BF16, "slices2rgb: bad dtype %d", dtype);

@@ -221,6 +221,12 @@ int launch_axpby_cols(const float* x, int64_t xs, const float* g, float alpha, f
                       int cols, hipStream_t s);
 int launch_im2col14(const void* vol, int dt, int n, int H, int W, float* col, hipStream_t s);
 int launch_pos_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, hipStream_t s);
+size_t znorm_state_bytes(void);
+int launch_pad_axis(float* v, int n0, int n1, int n2, int axis, int lo, int hi, int a0, int a1, int b0, int b1, int use_const,
+                    float cval, hipStream_t s);
+int launch_copy_block(const float* src, int sn1, int sn2, int s0, int s1, int s2, float* dst, int dn1, int dn2, int d0, int d1,
+                      int d2, int c0, int c1, int c2, hipStream_t s);
+int launch_znorm(const float* x, int64_t n, float q_lo, float q_hi, float* y, void* state, hipStream_t s);
 int launch_slices2rgb(const void* vol, int dt, int B, int D, int H, int W, void* out, hipStream_t s);
 int launch_mean_slices(const float* x, int B, int D, int E, float* out, hipStream_t s);
 int launch_readout(const float* cls_probs, const float* slice_probs, int B, int D, int heads, int N,

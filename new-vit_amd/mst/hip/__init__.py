@@ -80,6 +80,9 @@ SIGNATURES = {
     "mst_axpby_cols": (_i, [_vp, _i64, _vp, _f, _f, _vp, _i64, _i64, _i, _vp]),
     "mst_im2col14": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp_bwd": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "mst_crop_or_pad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "mst_znorm_state_bytes": (_sz, []),
+    "mst_znorm": (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
     "mst_slices2rgb": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_patch_embed": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mst_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i, _i, _i]),

@@ -406,6 +406,38 @@ def slices2rgb(tensor: Tensor) -> Tensor:
     return tensor.reshape(B, tensor.shape[2] // 3, 3, H, W).reshape(-1, 3, H, W)
 
 
+def crop_or_pad(x: Tensor, target_shape, padding_mode=0) -> Tensor:
+    """CropOrPad (augmentations_3d.py:144-195) with random_center=False on [C, a0, a1, a2]: bounds ini = ceil(n/2), fin = n - ini
+    (l.164-172); torchio 0.19.9's Pad is numpy.pad (mode 'minimum' or constant) on the spatial axes, then Crop."""
+    import numpy as np
+    a = x.numpy()
+    src = a.shape[1:]
+    tgt = [s if t is None else int(t) for t, s in zip(target_shape, src)]
+    diff = [t - s for t, s in zip(tgt, src)]
+    pads = [(0, 0)] + [((max(d, 0) + 1) // 2, max(d, 0) - (max(d, 0) + 1) // 2) for d in diff]
+    if any(p != (0, 0) for p in pads):
+        a = np.pad(a, pads, mode="minimum") if padding_mode == "minimum" else np.pad(a, pads, mode="constant", constant_values=padding_mode)
+    crops = [((max(-d, 0) + 1) // 2, max(-d, 0) - (max(-d, 0) + 1) // 2) for d in diff]
+    sl = (slice(None),) + tuple(slice(c0, a.shape[i + 1] - c1) for i, (c0, c1) in enumerate(crops))
+    return torch.from_numpy(np.ascontiguousarray(a[sl]))
+
+
+def znormalize(x: Tensor, percentiles=(0, 100)) -> Tensor:
+    """ZNormalization._znorm (augmentations_3d.py:73-86) for one channel with the datasets' masking method
+    (x > x.min()) & (x < x.max()) (dataset_3d_duke.py:43) + torchio's ZNormalization.znorm (mean / unbiased std of the masked values)."""
+    mask = (x > x.min()) & (x < x.max())
+    cutoff = torch.quantile(x.masked_select(mask).float(), torch.tensor(percentiles, dtype=torch.float32) / 100.0)
+    y = torch.clamp(x, *cutoff.to(x.dtype).tolist())
+    y = y.clone().float()
+    values = y[mask]
+    mean, std = values.mean(), values.std()
+    if std == 0:
+        raise RuntimeError("Standard deviation is 0 for masked values")
+    y -= mean
+    y /= std
+    return y
+
+
 def flops_per_volume(D: int, H: int, W: int, E: int = 384, depth: int = 12) -> float:
     """Algorithmic FLOPs of one forward: 2 FLOP per MAC, softmax/LN/GELU not counted."""
     Np = (H // PATCH) * (W // PATCH)

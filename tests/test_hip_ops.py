@@ -491,3 +491,37 @@ def test_slices2rgb_matches_reference_arithmetic(hip, dt, shape):
         for i in range(3):
             v = synth.synth_volume(tuple(int(u) for u in g[f"shape{i}"]), int(g[f"seed{i}"]))
             assert np.array_equal(slices2rgb(v.cuda()).cpu().numpy(), g[f"out{i}"])
+
+
+@pytest.mark.parametrize("mode", ["minimum", 0, -3.5])
+@pytest.mark.parametrize("src,tgt", [((5, 7, 9), (9, 12, 16)), ((12, 10, 8), (7, 5, 4)), ((6, 20, 9), (11, 8, 9)), ((3, 4, 5), (3, 4, 5)),
+                                     ((32, 150, 140), (32, 224, 224)), ((1, 9, 9), (4, 3, 12))])
+def test_crop_or_pad_matches_numpy_pad_semantics(hip, mode, src, tgt):
+    """8f-4: CropOrPad (augmentations_3d.py:144-195, centre mode) on the device, bit-exact against the oracle (numpy.pad itself)."""
+    from mst import preprocess
+    from oracle import mst_oracle as O
+    x = rnd((2, *src), 90, 3.0)
+    got = preprocess.crop_or_pad(x.cuda(), tgt, mode)
+    ref = O.crop_or_pad(x, tgt, mode)
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("shape,pct", [((1, 6, 40, 50), (0.5, 99.5)), ((1, 3, 17, 19), (0, 100)), ((1, 32, 224, 224), (0.5, 99.5)),
+                                       ((1, 4, 30, 30), (10, 60))])
+def test_znormalize_matches_reference_arithmetic(hip, shape, pct):
+    """8f-4: ZNormalization (augmentations_3d.py:40-86): the quantile cut-offs are exact order statistics (radix select), so they
+    match torch.quantile to the last bit of the interpolation; mean / std differ by summation order only."""
+    from mst import preprocess
+    from oracle import mst_oracle as O
+    x = rnd(shape, 91, 2.0) * 37.0 + 11.0
+    x[0, 0, :3, :3] = x.min() - 5            # background plateau below everything, a few saturated voxels above
+    x[0, -1, -2:, -2:] = x.max() + 9
+    got, st = preprocess.znormalize(x.cuda(), pct, return_stats=True)
+    ref = O.znormalize(x, pct)
+    mask = (x > x.min()) & (x < x.max())
+    cut = torch.quantile(x.masked_select(mask), torch.tensor(pct) / 100.0)
+    assert st["count"] == int(mask.sum())
+    assert abs(st["cut_lo"] - float(cut[0])) <= 1e-6 * abs(float(cut[0])) and abs(st["cut_hi"] - float(cut[1])) <= 1e-6 * abs(float(cut[1]))
+    assert float((got.cpu() - ref).abs().max()) < 2e-5
+    with pytest.raises(RuntimeError, match="Standard deviation is 0"):
+        preprocess.znormalize(torch.tensor([0.0, 1.0, 1.0, 1.0, 2.0]).reshape(1, 1, 1, 5).cuda())
