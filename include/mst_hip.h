@@ -125,6 +125,17 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
                     const float* bias, const float* prefix, int n_prefix, const float* pos_patch,
                     int E, float* x, mst_stream_t stream);
 
+/* Convolutional backbone of the ResNet models (reference mst/models/resnet.py:44-50,127-243 on torchvision's
+ * resnet34, which is not part of the reference tree: the published architecture is restated).  Activations are NHWC fp32, so a
+ * convolution (+ folded BatchNorm + ReLU / residual) is mst_im2col_nhwc followed by mst_gemm with the matching epilogue.
+ * mst_im2col_nhwc: x [n,H,W,C] -> col [n*Ho*Wo, Kpad], col[(n,oy,ox)][(ky,kx,c)] = x[n][oy*stride-pad+ky][ox*stride-pad+kx][c],
+ *   zero outside the image and for k >= kh*kw*C.  mst_maxpool_nhwc: 3x3, stride 2, padding 1 (the resnet stem).
+ * mst_avgpool_nhwc: x [n, HW, C] -> y [n, C], the adaptive average pool to 1x1. */
+int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* col,
+                    mst_stream_t stream);
+int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);
+int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream);
+
 /* Input pipeline in front of the model (reference mst/data/datasets/augmentations/augmentations_3d.py on
  * torchio 0.19.9, which is not part of the reference tree: restated from its published algorithm, numpy.pad semantics included).
  * mst_crop_or_pad: CropOrPad (l.144-195) with the deterministic centre (random_center=False: ini = ceil(n/2), fin = n - ini per

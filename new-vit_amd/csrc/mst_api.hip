@@ -219,6 +219,21 @@ int mst_pos_embed_interp_bwd(const float* dout, int M, int E, int gh, int gw, do
     return launch_pos_interp_bwd(dout, M, E, gh, gw, offset, dpos, (hipStream_t)stream);
 }
 
+// ---- convolutional backbone of the ResNet models ------------------------------------------------------------
+int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* col,
+                    mst_stream_t stream) {
+    MST_CHECK_ARG(x && col && n > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "im2col_nhwc: bad arguments");
+    return launch_im2col_nhwc(x, n, H, W, C, kh, kw, stride, pad, Kpad, col, (hipStream_t)stream);
+}
+int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
+    MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");
+    return launch_maxpool_nhwc(x, n, H, W, C, y, (hipStream_t)stream);
+}
+int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream) {
+    MST_CHECK_ARG(x && y && n > 0 && HW > 0 && C > 0, "avgpool_nhwc: bad arguments");
+    return launch_avgpool_nhwc(x, n, HW, C, y, (hipStream_t)stream);
+}
+
 // ---- input pipeline ------------------------------------------------------------------------------------
 int mst_crop_or_pad(const float* src, int s0, int s1, int s2, float* dst, int t0, int t1, int t2, int pad_minimum,
                     float pad_value, void* ws, size_t ws_bytes, mst_stream_t stream) {

@@ -221,6 +221,11 @@ int launch_axpby_cols(const float* x, int64_t xs, const float* g, float alpha, f
                       int cols, hipStream_t s);
 int launch_im2col14(const void* vol, int dt, int n, int H, int W, float* col, hipStream_t s);
 int launch_pos_interp_bwd(const float* dout, int M, int E, int gh, int gw, double offset, float* dpos, hipStream_t s);
+// convolutional backbone (k_conv.hip)
+int launch_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* col,
+                       hipStream_t s);
+int launch_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, hipStream_t s);
+int launch_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, hipStream_t s);
 size_t znorm_state_bytes(void);
 int launch_pad_axis(float* v, int n0, int n1, int n2, int axis, int lo, int hi, int a0, int a1, int b0, int b1, int use_const,
                     float cval, hipStream_t s);

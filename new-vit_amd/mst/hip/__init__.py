@@ -80,6 +80,9 @@ SIGNATURES = {
     "mst_axpby_cols": (_i, [_vp, _i64, _vp, _f, _f, _vp, _i64, _i64, _i, _vp]),
     "mst_im2col14": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp_bwd": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
+    "mst_im2col_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_crop_or_pad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "mst_znorm_state_bytes": (_sz, []),
     "mst_znorm": (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
@@ -522,6 +525,35 @@ def pos_embed_interp_bwd(dout: torch.Tensor, M: int, gh: int, gw: int, offset: f
     E = dout.shape[-1]
     _check(load().mst_pos_embed_interp_bwd(ptr(dout), M, E, gh, gw, offset, ptr(dpos), stream_of(dout)), "mst_pos_embed_interp_bwd")
     return dpos
+
+
+# ---- convolutional backbone ops (NHWC fp32) --------------------------------------------------------------------------
+def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, kpad: Optional[int] = None) -> torch.Tensor:
+    """x [n,H,W,C] fp32 -> col [n*Ho*Wo, Kpad] (K = kh*kw*C in (ky,kx,c) order, zero-padded to Kpad)."""
+    _dev(x, "im2col_nhwc")
+    n, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = kh * kw * Cc
+    kpad = kpad or (K + 15) // 16 * 16
+    col = torch.empty((n * Ho * Wo, kpad), dtype=torch.float32, device=x.device)
+    _check(load().mst_im2col_nhwc(ptr(x), n, H, W, Cc, kh, kw, stride, pad, kpad, ptr(col), stream_of(x)), "mst_im2col_nhwc")
+    return col
+
+
+def maxpool_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "maxpool_nhwc")
+    n, H, W, Cc = x.shape
+    y = torch.empty((n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+    _check(load().mst_maxpool_nhwc(ptr(x), n, H, W, Cc, ptr(y), stream_of(x)), "mst_maxpool_nhwc")
+    return y
+
+
+def avgpool_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "avgpool_nhwc")
+    n, H, W, Cc = x.shape
+    y = torch.empty((n, Cc), dtype=torch.float32, device=x.device)
+    _check(load().mst_avgpool_nhwc(ptr(x), n, H * W, Cc, ptr(y), stream_of(x)), "mst_avgpool_nhwc")
+    return y
 
 
 class Profiler:

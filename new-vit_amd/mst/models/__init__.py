@@ -1,8 +1,9 @@
 """Import surface of the reference's ``mst.models`` package (mst/models/__init__.py:1-2; scripts/main_train.py:18-19 and
 scripts/main_predict.py:27-28 import from here and from the sub-modules).
 
-``DinoV2ClassifierSlice`` is the MI355X hot path; ``DinoV3ClassifierSlice``, ``ResNet`` and ``ResNetSliceTrans`` exist so that
-the scripts' imports and ``isinstance`` dispatch keep working (they raise on construction: out of scope).
+``DinoV2ClassifierSlice`` is the MI355X hot path; ``ResNet`` / ``ResNetSliceTrans`` run their inference forward on HIP kernels too
+(models/resnet.py); ``DinoV3ClassifierSlice`` exists so that the scripts' imports and ``isinstance`` dispatch keep working (it raises
+on construction: out of scope).
 """
 from pkgutil import extend_path
 

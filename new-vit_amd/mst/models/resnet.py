@@ -1,22 +1,341 @@
-"""Placeholders for the reference's ResNet models (mst/models/resnet.py).
+"""MI355X-native ``ResNet`` / ``ResNetSliceTrans`` -- the inference path of the reference's mst/models/resnet.py:27-243
+(BASELINE configs[3] names the model).
 
-`ResNet` / `ResNetSliceTrans` are a "next" row of the scope contract: their
-torchvision / MONAI backbones are not part of the reference tree and have no HIP path yet.  The
-classes exist so that `from mst.models.resnet import ResNet, ResNetSliceTrans` and the
-`isinstance` dispatch of scripts/main_predict.py:136-143 keep working; constructing one fails loudly.
+Same constructors, ``forward`` signatures, getters and ``state_dict`` keys as the reference's 2-D torchvision branch
+(``self.model`` = torchvision ``resnet{18,34}`` with ``fc`` replaced: resnet.py:44-50; ``ResNetSliceTrans`` adds the Slice
+Transformer with 16 heads over 512-wide slice embeddings, ``cls_token`` and ``linear``: resnet.py:146-166).  The modules below are
+parameter containers; the arithmetic runs in HIP kernels through the C ABI:
+
+  backbone   NHWC fp32 activations; every convolution = ``mst_im2col_nhwc`` + the exact-fp32 MFMA GEMM (``mst_gemm``) with eval-mode
+             BatchNorm folded into weight and bias and ReLU / the residual add in the GEMM epilogue; ``mst_maxpool_nhwc``,
+             ``mst_avgpool_nhwc``.  Gray -> RGB (``x.repeat(1, 3, ...)``, resnet.py:176) is folded into conv1 (the three input
+             channels are identical, so their kernels are summed).
+  fusion     ``mst_slice_fusion`` -- the kernels of DinoV2ClassifierSlice's Slice Transformer with nhead 16, E 512.
+
+torchvision's source is not part of the reference tree: the published resnet architecture is restated, parity of
+the backbone is against ``oracle/resnet_oracle.py`` (plain torch ops) and therefore UNPINNED; the fusion half is pinned by a
+fixture of the reference's own ``TransformerEncoderLayer`` (tests/golden/resnet_fusion.npz).
+
+Not built (raise): the training step of the backbone (BatchNorm batch statistics, convolution backward) and with it Grad-CAM++
+(``save_attn`` on the backbone, resnet.py:62-122), the MONAI branches (3-D, and ``pretrained=False`` in the reference), bottleneck
+ResNets (model >= 50).  ``pretrained=True`` needs torchvision's weights (network / hub cache); when torchvision is absent the tree
+is initialised like torchvision's and a warning says so -- a checkpoint's ``state_dict`` replaces it anyway.
 """
+from __future__ import annotations
+
+import math
+import warnings
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
 from .base_model import BasicClassifier
+from .. import hip
+
+_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_WIDTHS = [64, 128, 256, 512]
+
+
+class _P(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the forward runs in libmst_hip.so")
+
+
+class _Conv(_P):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")      # torchvision resnet.py init
+
+
+class _BN(_P):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = 1e-5
+
+
+class _Linear(_P):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.uniform_(self.bias, -1 / math.sqrt(cin), 1 / math.sqrt(cin))
+
+
+class _BasicBlock(_P):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv(cin, cout, 3), _BN(cout)
+        self.conv2, self.bn2 = _Conv(cout, cout, 3), _BN(cout)
+        self.stride = stride
+        if stride != 1 or cin != cout:
+            self.downsample = nn.ModuleList([_Conv(cin, cout, 1), _BN(cout)])       # keys downsample.0.* / downsample.1.*
+
+
+class _TVResNet(_P):
+    """Parameter tree of torchvision.models.resnet{18,34} (keys conv1, bn1, layer1..4.<i>.*, fc)."""
+
+    def __init__(self, model: int, fc_out: Optional[int]):
+        super().__init__()
+        if model not in _LAYERS:
+            raise NotImplementedError(f"resnet{model}: only the BasicBlock models (18, 34) are built on the HIP path")
+        self.conv1, self.bn1 = _Conv(3, 64, 7), _BN(64)
+        cin = 64
+        for li, (n, w) in enumerate(zip(_LAYERS[model], _WIDTHS)):
+            blocks = []
+            for b in range(n):
+                blocks.append(_BasicBlock(cin, w, 2 if (b == 0 and li > 0) else 1))
+                cin = w
+            setattr(self, f"layer{li + 1}", nn.ModuleList(blocks))
+        self.out_features = cin
+        self.fc = nn.Identity() if fc_out is None else _Linear(cin, fc_out)
+
+
+def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev):
+    """Eval-mode BatchNorm folded into the convolution: GEMM weight [Cout, Kpad] in (ky, kx, c) order + bias [Cout]."""
+    w = conv.weight.detach().to(dev, torch.float32)
+    if sum_in:
+        w = w.sum(dim=1, keepdim=True)                   # identical input channels (gray -> RGB repeat): one summed kernel
+    s = bn.weight.detach().to(dev, torch.float32) / torch.sqrt(bn.running_var.to(dev, torch.float32) + bn.eps)
+    b = bn.bias.detach().to(dev, torch.float32) - bn.running_mean.to(dev, torch.float32) * s
+    w = (w * s[:, None, None, None]).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    K = w.shape[1]
+    kpad = (K + 15) // 16 * 16
+    if kpad != K:
+        w = torch.cat([w, w.new_zeros(w.shape[0], kpad - K)], dim=1)
+    return w.contiguous(), b.contiguous(), kpad
 
 
 class ResNet(BasicClassifier):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError(
-            "mst.models.resnet.ResNet has no MI355X-native implementation yet (SURVEY.md 8f-2); "
-            "only DinoV2ClassifierSlice is built on the HIP path")
+    def __init__(self, in_ch, out_ch, spatial_dims=3, model=34, pretrained=False, kwargs_resnet={}, **kwargs):
+        emb_ch = kwargs.pop("emb_ch", out_ch)
+        self.chunk_images = int(kwargs.pop("chunk_images", 16))       # build-specific: images per backbone pass (activation memory)
+        super().__init__(in_ch, out_ch, spatial_dims, **kwargs)
+        self.attention_maps = []
+        if spatial_dims != 2:
+            raise NotImplementedError("ResNet: only the 2-D (torchvision) branch of the reference is built on the HIP path; the 3-D "
+                                      "MONAI branch is not (SURVEY.md 8f-2)")
+        fc_out = None if emb_ch is None else emb_ch
+        self.model = _TVResNet(model, fc_out)
+        if pretrained:
+            try:                                         # reference resnet.py:44-45: torchvision weights="DEFAULT" (network / hub cache)
+                import torchvision.models as tvm
+                tv = getattr(tvm, f"resnet{model}")(weights="DEFAULT")
+                sd = {k: v for k, v in tv.state_dict().items() if not k.startswith("fc.") or (emb_ch == 1000)}
+                self.model.load_state_dict(sd, strict=False)
+            except Exception as e:  # pragma: no cover - torchvision is not in this image
+                warnings.warn(f"ResNet(pretrained=True): torchvision weights unavailable ({type(e).__name__}); the backbone keeps "
+                              "torchvision's random initialisation until a checkpoint is loaded")
+        else:
+            warnings.warn("ResNet(pretrained=False): the reference builds a MONAI resnet here; this build keeps the torchvision "
+                          "parameter layout with torchvision's initialisation")
+        self._prep = None
+        self._epoch = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    def _invalidate(self):
+        self._prep = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._prep = None
+        return super()._apply(fn, *args, **kwargs)
+
+    # ---- backbone -------------------------------------------------------------------------------------------------------
+    def _prepare(self, sum_in: bool):
+        key = (sum_in, str(self.device))
+        if self._prep is not None and self._prep["key"] == key:
+            return self._prep
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"ResNet runs on an MI355X only: parameters are on {dev}; call .to('cuda'). There is no CPU fallback.")
+        m = self.model
+        prep = {"key": key, "stem": _fold(m.conv1, m.bn1, sum_in, dev), "blocks": []}
+        for li in range(4):
+            for blk in getattr(m, f"layer{li + 1}"):
+                e = {"stride": blk.stride, "c1": _fold(blk.conv1, blk.bn1, False, dev), "c2": _fold(blk.conv2, blk.bn2, False, dev)}
+                if hasattr(blk, "downsample"):
+                    e["ds"] = _fold(blk.downsample[0], blk.downsample[1], False, dev)
+                prep["blocks"].append(e)
+        if not isinstance(m.fc, nn.Identity):
+            prep["fc"] = (m.fc.weight.detach().to(dev, torch.float32).contiguous(), m.fc.bias.detach().to(dev, torch.float32).contiguous())
+        self._prep = prep
+        return prep
+
+    def _features(self, x_nhwc: torch.Tensor, sum_in: bool) -> torch.Tensor:
+        """[n, H, W, C] fp32 on the device -> [n, 512] (avgpool output, before fc)."""
+        p = self._prepare(sum_in)
+        outs: List[torch.Tensor] = []
+        for i0 in range(0, x_nhwc.shape[0], self.chunk_images):
+            x = x_nhwc[i0:i0 + self.chunk_images].contiguous()
+            n, H, W, _ = x.shape
+            w, b, kpad = p["stem"]
+            Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            y = hip.gemm(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), w, b, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, 64)
+            y = hip.maxpool_nhwc(y)
+            for e in p["blocks"]:
+                n, H, W, Cin = y.shape
+                s = e["stride"]
+                Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+                w1, b1, k1 = e["c1"]
+                h1 = hip.gemm(hip.im2col_nhwc(y, 3, 3, s, 1, k1), w1, b1, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w1.shape[0])
+                if "ds" in e:
+                    wd, bd, kd = e["ds"]
+                    idt = hip.gemm(hip.im2col_nhwc(y, 1, 1, s, 0, kd), wd, bd, epilogue=hip.EPI_BIAS)
+                else:
+                    idt = y.reshape(n * H * W, Cin).clone()
+                w2, b2, k2 = e["c2"]
+                hip.gemm(hip.im2col_nhwc(h1, 3, 3, 1, 1, k2), w2, b2, epilogue=hip.EPI_RESIDUAL, out=idt)      # identity + bn2(conv2(.))
+                hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))          # ReLU in place
+                y = idt.view(n, Ho, Wo, w2.shape[0])
+            outs.append(hip.avgpool_nhwc(y))
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+    def forward(self, source, save_attn=False, **kwargs):
+        if save_attn:
+            raise NotImplementedError("ResNet(save_attn=True): Grad-CAM++ (resnet.py:62-122) needs the backbone's backward pass, "
+                                      "which is not on the HIP path yet (SURVEY.md 8f-2)")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("ResNet: the training step of the convolutional backbone (BatchNorm batch statistics, "
+                                      "convolution backward) is not on the HIP path yet; run the forward under torch.no_grad() / eval()")
+        x = source.to(self.device)                       # [N, C, H, W]
+        if x.dim() != 4:
+            raise RuntimeError(f"Expected 4D input [N, C, H, W] to the 2-D resnet, got {tuple(x.shape)}")
+        if x.shape[1] != 3:
+            raise RuntimeError(f"Given groups=1, weight of size [64, 3, 7, 7], expected input{list(x.shape)} to have 3 channels, "
+                               f"but got {x.shape[1]} channels instead")
+        feat = self._features(x.float().permute(0, 2, 3, 1).contiguous(), False)
+        p = self._prep
+        if "fc" in p:
+            return hip.gemm(feat, p["fc"][0], p["fc"][1], epilogue=hip.EPI_BIAS)
+        return feat
+
+    def get_attention_maps(self):
+        if not self.attention_maps:
+            raise NotImplementedError("Grad-CAM++ attention maps need the backbone's backward pass (not on the HIP path yet)")
+        return self.attention_maps[-1]
 
 
-class ResNetSliceTrans(BasicClassifier):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError(
-            "mst.models.resnet.ResNetSliceTrans has no MI355X-native implementation yet (SURVEY.md 8f-2); "
-            "only DinoV2ClassifierSlice is built on the HIP path")
+SLICE_HEADS = 16      # reference resnet.py:151
+
+
+class _SliceLayer(_P):
+    def __init__(self, E):
+        super().__init__()
+        holder = _P()
+        holder.in_proj_weight = nn.Parameter(torch.empty(3 * E, E))
+        holder.in_proj_bias = nn.Parameter(torch.zeros(3 * E))
+        holder.out_proj = _Linear(E, E)
+        nn.init.xavier_uniform_(holder.in_proj_weight)
+        nn.init.zeros_(holder.out_proj.bias)
+        self.self_attn = holder
+        self.linear1, self.linear2 = _Linear(E, E), _Linear(E, E)
+        self.norm1, self.norm2 = _LN(E), _LN(E)
+
+
+class _LN(_P):
+    def __init__(self, E):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(E))
+        self.bias = nn.Parameter(torch.zeros(E))
+
+
+class _SliceFusion(_P):
+    def __init__(self, E):
+        super().__init__()
+        self.layers = nn.ModuleList([_SliceLayer(E)])
+        self.norm = _LN(E)
+
+
+class ResNetSliceTrans(ResNet):
+    def __init__(self, in_ch, out_ch, spatial_dims=2, model=34, pretrained=True, kwargs_resnet={},
+                 rotary_positional_encoding=None, optimizer_kwargs={"lr": 1e-5, "weight_decay": 1e-2}, **kwargs):
+        super().__init__(in_ch, out_ch, spatial_dims, emb_ch=None, model=model, pretrained=pretrained, kwargs_resnet=kwargs_resnet,
+                         optimizer_kwargs=optimizer_kwargs, **kwargs)
+        if rotary_positional_encoding is not None:
+            raise NotImplementedError("ResNetSliceTrans: rotary variants are wired for DinoV2ClassifierSlice only")
+        emb_ch = 512 if model <= 34 else 2048
+        self.emb_ch = emb_ch
+        self.attention_maps_slice = []
+        self.slice_fusion = _SliceFusion(emb_ch)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, emb_ch))
+        self.linear = _Linear(emb_ch, out_ch)
+        self._fw = None
+
+    def _invalidate(self):
+        self._prep = None
+        self._fw = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._fw = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _fusion_weights(self):
+        if self._fw is not None:
+            return self._fw
+        dev = self.device
+        keep = []
+
+        def f32(t):
+            t = t.detach().to(dev, torch.float32).contiguous()
+            keep.append(t)
+            return hip.ptr(t)
+
+        lay = self.slice_fusion.layers[0]
+        fw = hip.FusionWeights()
+        fw.emb_in = fw.emb = self.emb_ch
+        fw.num_heads, fw.fusion_type, fw.out_ch = SLICE_HEADS, hip.FUSION_TRANSFORMER, self.out_ch
+        fw.cls_token = f32(self.cls_token.reshape(-1))
+        fw.ln1_w, fw.ln1_b = f32(lay.norm1.weight), f32(lay.norm1.bias)
+        fw.in_proj_w, fw.in_proj_b = f32(lay.self_attn.in_proj_weight), f32(lay.self_attn.in_proj_bias)
+        fw.out_proj_w, fw.out_proj_b = f32(lay.self_attn.out_proj.weight), f32(lay.self_attn.out_proj.bias)
+        fw.ln2_w, fw.ln2_b = f32(lay.norm2.weight), f32(lay.norm2.bias)
+        fw.lin1_w, fw.lin1_b = f32(lay.linear1.weight), f32(lay.linear1.bias)
+        fw.lin2_w, fw.lin2_b = f32(lay.linear2.weight), f32(lay.linear2.bias)
+        fw.norm_w, fw.norm_b = f32(self.slice_fusion.norm.weight), f32(self.slice_fusion.norm.bias)
+        fw.head_w, fw.head_b, fw.head_in = f32(self.linear.weight), f32(self.linear.bias), self.emb_ch
+        self._fw = (fw, keep)
+        return self._fw
+
+    def fuse(self, emb: torch.Tensor, B: int, D: int, src_key_padding_mask=None, save_attn: bool = False) -> torch.Tensor:
+        """[B*D, 512] slice embeddings -> logits [B, out_ch] (resnet.py:180-191)."""
+        fw, _ = self._fusion_weights()
+        dev = emb.device
+        feats = torch.empty((B, self.emb_ch), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, self.out_ch), dtype=torch.float32, device=dev)
+        probs = torch.empty((B, SLICE_HEADS, D + 1, D + 1), dtype=torch.float32, device=dev) if save_attn else None
+        m = None
+        if src_key_padding_mask is not None:
+            m = src_key_padding_mask.to(dev).to(torch.uint8).contiguous()
+        ws = torch.empty(int(hip.fusion_workspace_bytes(fw, B, D)), dtype=torch.uint8, device=dev)
+        hip.slice_fusion(fw, emb.contiguous(), B, D, m, feats, logits, probs, ws)
+        if save_attn:
+            self.attention_maps_slice = [probs]
+        return logits
+
+    def forward(self, source, src_key_padding_mask=None, **kwargs):
+        save_attn = bool(kwargs.get("save_attn"))
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("ResNetSliceTrans: the training step (BASELINE configs[3]) needs the backbone's backward pass, "
+                                      "which is not on the HIP path yet (SURVEY.md 8f-2); inference runs under torch.no_grad() / eval()")
+        x = source.to(self.device)                       # [B, C, D, H, W]
+        B, C, D, H, W = x.shape
+        if C != 1:                                       # x.repeat(1, 3, ...) then a 3-channel conv1: only gray volumes fit (resnet.py:176)
+            raise RuntimeError(f"Given groups=1, weight of size [64, 3, 7, 7], expected input[{B * D}, {3 * C}, {H}, {W}] to have 3 "
+                               f"channels, but got {3 * C} channels instead")
+        self._last_shape = (B, D)
+        emb = self._features(x.float().reshape(B * D, H, W, 1).contiguous(), True)      # 'b c d h w -> (b d) c h w', gray -> RGB folded
+        return self.fuse(emb, B, D, src_key_padding_mask, save_attn)
+
+    def get_slice_attention(self):
+        B, D = self._last_shape
+        sp = self.attention_maps_slice[-1].contiguous()                              # [B, heads, 1+D, 1+D]
+        out = torch.empty((B * D,), dtype=torch.float32, device=sp.device)
+        hip.attention_readout(None, sp, B, D, 1, 2, 0, SLICE_HEADS, None, out, None)
+        return out[:, None, None]                        # [B*D, 1, 1]  (resnet.py:196-205)

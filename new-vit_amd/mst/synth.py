@@ -175,3 +175,66 @@ def state_dict_digest(sd) -> str:
         h.update(str(tuple(v.shape)).encode())
         h.update(v.detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+_RESNET_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+
+
+def synth_resnet_state_dict(seed: int = 0, model: int = 34, out_ch: int = 2, slice_trans: bool = True,
+                            fc_out: int | None = None) -> "OrderedDict[str, torch.Tensor]":
+    """``ResNetSliceTrans.state_dict()`` (``slice_trans=True``: ``model.*`` = torchvision resnet layout with ``fc`` = Identity,
+    plus ``slice_fusion.*``, ``cls_token``, ``linear.*``: reference resnet.py:146-166) or ``ResNet.state_dict()`` with
+    ``model.fc`` = Linear(512, fc_out).  BatchNorm statistics are non-trivial so that the folding is exercised."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def conv(k, cout, cin, ks):
+        sd[k + ".weight"] = _t(k + ".weight", (cout, cin, ks, ks), seed, math.sqrt(2.0 / (cin * ks * ks)))
+
+    def bn(k, c):
+        sd[k + ".weight"] = _t(k + ".weight", (c,), seed, 0.1, 1.0)
+        sd[k + ".bias"] = _t(k + ".bias", (c,), seed, 0.1)
+        sd[k + ".running_mean"] = _t(k + ".running_mean", (c,), seed, 0.2)
+        sd[k + ".running_var"] = _t(k + ".running_var", (c,), seed, 0.2, 1.0).abs() + 0.1
+        sd[k + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    conv("model.conv1", 64, 3, 7)
+    bn("model.bn1", 64)
+    cin = 64
+    for li, (n, w) in enumerate(zip(_RESNET_LAYERS[model], (64, 128, 256, 512))):
+        for b in range(n):
+            p = f"model.layer{li + 1}.{b}"
+            stride = 2 if (b == 0 and li > 0) else 1
+            conv(p + ".conv1", w, cin, 3)
+            bn(p + ".bn1", w)
+            conv(p + ".conv2", w, w, 3)
+            bn(p + ".bn2", w)
+            if stride != 1 or cin != w:
+                conv(p + ".downsample.0", w, cin, 1)
+                bn(p + ".downsample.1", w)
+            cin = w
+    E = 512
+
+    def lin(k, out_f, in_f, gain=1.0):
+        sd[k + ".weight"] = _t(k + ".weight", (out_f, in_f), seed, gain / math.sqrt(in_f))
+        sd[k + ".bias"] = _t(k + ".bias", (out_f,), seed, 0.05)
+
+    def ln(k):
+        sd[k + ".weight"] = _t(k + ".weight", (E,), seed, 0.1, 1.0)
+        sd[k + ".bias"] = _t(k + ".bias", (E,), seed, 0.1)
+
+    if not slice_trans:
+        if fc_out is not None:
+            lin("model.fc", fc_out, E)
+        return sd
+    p = "slice_fusion.layers.0"
+    sd[p + ".self_attn.in_proj_weight"] = _t(p + ".self_attn.in_proj_weight", (3 * E, E), seed, 1.2 / math.sqrt(E))
+    sd[p + ".self_attn.in_proj_bias"] = _t(p + ".self_attn.in_proj_bias", (3 * E,), seed, 0.05)
+    lin(p + ".self_attn.out_proj", E, E, 0.8)
+    lin(p + ".linear1", E, E)
+    lin(p + ".linear2", E, E, 0.8)
+    ln(p + ".norm1")
+    ln(p + ".norm2")
+    ln("slice_fusion.norm")
+    sd["cls_token"] = _t("cls_token", (1, 1, E), seed, 0.5)
+    lin("linear", out_ch, E)
+    return sd

@@ -237,13 +237,13 @@ def liere_rotate(t: Tensor, R: Tensor, axes_length: int = 33) -> Tensor:
 
 
 def slice_fusion(sd: SD, x: Tensor, key_padding_mask: Optional[Tensor] = None,
-                 rotary: Optional[str] = None) -> Tuple[Tensor, Tensor]:
+                 rotary: Optional[str] = None, heads: int = SLICE_HEADS) -> Tuple[Tensor, Tensor]:
     """nn.TransformerEncoder(1 x TransformerEncoderLayer(norm_first), norm=LayerNorm)
     (dino.py:84-96; transformer_blocks.py:565-587,29-318).  x = [B,L,E] with CLS at 0;
     key_padding_mask bool [B,L], True = ignore.  Returns (y [B,L,E], probs [B,12,L,L])."""
     p = "slice_fusion.layers.0"
     B, L, E = x.shape
-    h, hd = SLICE_HEADS, E // SLICE_HEADS
+    h, hd = heads, E // heads
     y = layer_norm(x, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
     qkv = F.linear(y, sd[p + ".self_attn.in_proj_weight"], sd[p + ".self_attn.in_proj_bias"])
     q, k, v = (t.reshape(B, L, h, hd).transpose(1, 2) for t in qkv.chunk(3, dim=-1))  # [B,h,L,hd]

@@ -65,9 +65,20 @@ def test_module_surface_and_state_dict_layouts():
         assert set(mm.state_dict()) == set(ref), kw
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 2, 28, 28))
-    for cls in (ResNet, ResNetSliceTrans, DinoV3ClassifierSlice):
-        with pytest.raises(NotImplementedError):
-            cls(in_ch=1, out_ch=2)
+    with pytest.raises(NotImplementedError):
+        DinoV3ClassifierSlice(in_ch=1, out_ch=2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rs = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False)                     # main_predict.py:138-139 isinstance dispatch
+        rn = ResNet(in_ch=3, out_ch=2, spatial_dims=2, pretrained=False, model=34)     # reference tests/models/test_resnet.py
+    assert isinstance(rs, ResNet)
+    ref_keys = set(synth.synth_resnet_state_dict(0, 34, 2))
+    assert {k for k in rs.state_dict() if not k.startswith(("auc_roc", "acc."))} == ref_keys
+    assert {k for k in rn.state_dict() if not k.startswith(("auc_roc", "acc."))} == set(synth.synth_resnet_state_dict(0, 34, 2, slice_trans=False, fc_out=2))
+    rs.load_state_dict(synth.synth_resnet_state_dict(1, 34, 2), strict=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
+        rs.eval()(torch.zeros(1, 1, 2, 32, 32))
 
 
 def test_checkpoint_roundtrip(tmp_path):

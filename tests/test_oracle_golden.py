@@ -217,3 +217,18 @@ def test_slices2rgb_restatement_matches_reference_fixture(golden):
     for i in range(3):
         x = synth.synth_volume(tuple(int(v) for v in g[f"shape{i}"]), int(g[f"seed{i}"]))
         assert np.array_equal(O.slices2rgb(x).numpy(), g[f"out{i}"])
+
+
+def test_resnet_fusion_restatement_matches_reference_fixture(golden):
+    """8f-2: the across-slice half of ResNetSliceTrans (16 heads, E 512) as restated by oracle/resnet_oracle.py against what the
+    reference's own TransformerEncoderLayer produced."""
+    from oracle import resnet_oracle as R
+    g = golden("resnet_fusion")
+    sd = synth.synth_resnet_state_dict(int(g["seed"]), 34, 2)
+    emb = torch.from_numpy(g["emb"])
+    B, D, E = emb.shape
+    for tag, m in (("", None), ("_masked", torch.from_numpy(g["src_key_padding_mask"]))):
+        out = R.fuse(sd, emb.reshape(B * D, E), B, D, m)
+        assert np.abs(out["logits"].numpy() - g["logits" + tag]).max() < 1e-5
+        assert np.abs(out["features"].numpy() - g["features" + tag]).max() < 1e-5
+        assert np.abs(out["slice_map"].numpy() - g["slice_map" + tag]).max() < 1e-6

@@ -351,6 +351,41 @@ def case_hub_reg(synth, name, seed):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def case_resnet_fusion(dino, synth):
+    """The across-slice half of ResNetSliceTrans (reference resnet.py:146-166,180-191) built from the reference's own
+    TransformerEncoderLayer(d_model=512, nhead=16, dim_feedforward=512, norm_first) + final LayerNorm, cls_token, linear head,
+    on synthetic slice embeddings.  (The class itself cannot be constructed here: torchvision / MONAI are absent.)"""
+    tb = importlib.import_module("refmst.models.utils.transformer_blocks")
+    sd = synth.synth_resnet_state_dict(21, 34, 2)
+    layer = tb.TransformerEncoderLayer(d_model=512, nhead=16, dim_feedforward=512, dropout=0.0, batch_first=True, norm_first=True,
+                                       rotary_positional_encoding=None)
+    enc = nn.TransformerEncoder(layer, num_layers=1, norm=nn.LayerNorm(512)).eval()
+    enc.load_state_dict({k[len("slice_fusion."):]: v for k, v in sd.items() if k.startswith("slice_fusion.")})
+    B, D = 2, 7
+    emb = torch.from_numpy(synth.hash_normal((B, D, 512), 22, 4)) * 0.8
+    mask = torch.zeros(B, D, dtype=torch.bool)
+    mask[1, 4:] = True
+    out = {"seed": np.array(21), "emb": np_(emb), "src_key_padding_mask": mask.numpy()}
+    lin = nn.Linear(512, 2)
+    lin.load_state_dict({"weight": sd["linear.weight"], "bias": sd["linear.bias"]})
+    with torch.no_grad():
+        for tag, m in (("", None), ("_masked", mask)):
+            x = torch.cat([sd["cls_token"].repeat(B, 1, 1), emb], dim=1)                    # resnet.py:180
+            mm = None if m is None else torch.cat([torch.zeros(B, 1, dtype=torch.bool), m], dim=1)
+            y = enc(x, src_key_padding_mask=mm)[:, 0]                                       # resnet.py:187-188
+            out["features" + tag] = np_(y)
+            out["logits" + tag] = np_(lin(y))
+            mha = enc.layers[0].self_attn
+            yn = enc.layers[0].norm1(x)
+            _, w = mha(yn, yn, yn, need_weights=True, average_attn_weights=False, key_padding_mask=mm)
+            out["slice_map" + tag] = np_(w)
+            a = w[:, :, 0, 1:].clone()                                                      # get_slice_attention, resnet.py:196-205
+            a /= a.sum(dim=-1, keepdim=True)
+            out["slice_attention" + tag] = np_(a.mean(dim=1).view(-1)[:, None, None])
+    np.savez_compressed(GOLD / "resnet_fusion.npz", **out)
+    print("wrote resnet_fusion.npz")
+
+
 def case_slices2rgb(dino, synth):
     """slices2rgb (reference dino.py:10-27) on seed-generated volumes: D % 3 = 1, 0 and 2."""
     out = {}
@@ -397,6 +432,7 @@ def main():
         "hub_reg": lambda: case_hub_reg(synth, "hub_reg", 12),
         "rollout_1x3x84": lambda: case_rollout(dino, synth, "rollout_1x3x84", (1, 1, 3, 84, 84), 8),
         "slices2rgb": lambda: case_slices2rgb(dino, synth),
+        "resnet_fusion": lambda: case_resnet_fusion(dino, synth),
     }
     for name, fn in cases.items():
         if args.only and name not in args.only:
