@@ -135,6 +135,30 @@ int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, 
                     mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);
 int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream);
+/* Training step of the backbone (BASELINE configs[3]; what torch.autograd + nn.BatchNorm2d(train) do for the reference):
+ * mst_batchnorm_train: z [rows, C] (raw convolution output) -> y = gamma (z - mean) rstd + beta (+ residual) (ReLU if relu) with the
+ *   BATCH statistics (biased variance); mean / rstd [C] are kept for the backward; running_mean / running_var (nullable) are
+ *   updated as nn.BatchNorm2d does (momentum, unbiased variance); scratch: C floats.
+ * mst_batchnorm_bwd: dgamma, dbeta (+=, zero them first) and dz = gamma rstd (dy - dbeta/rows - xhat dgamma/rows).
+ * mst_col2im_nhwc: adjoint of mst_im2col_nhwc, dx += (fp32 atomics; zero dx first): dX of a convolution = col2im(dZ . W).
+ * mst_maxpool_bwd_nhwc (gradient to the first maximum of each window), mst_avgpool_bwd_nhwc. */
+int mst_batchnorm_train(const float* z, int64_t rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                        const float* residual, int relu, float* y, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float* scratch, mst_stream_t stream);
+int mst_batchnorm_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* dy, int64_t rows, int C,
+                      float* dgamma, float* dbeta, float* dz, mst_stream_t stream);
+int mst_col2im_nhwc(const float* dcol, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* dx,
+                    mst_stream_t stream);
+int mst_maxpool_bwd_nhwc(const float* x, const float* dy, int n, int H, int W, int C, float* dx, mst_stream_t stream);
+int mst_avgpool_bwd_nhwc(const float* dy, int n, int HW, int C, float* dx, mst_stream_t stream);
+/* Grad-CAM++ map of the backbone's last ReLU output (reference mst/models/resnet.py:93-118 compute_attention_maps /
+ * compute_grad_cam_weights, the map get_attention_maps returns): act [n, HW, C] fp32 NHWC; out [n, O] = the model output whose
+ * per-image maximum is the loss (resnet.py:66-68); W [O, C] = the fc weight, or NULL when the output IS the pooled features
+ * (O == C).  d loss / d pooled features = W[argmax] (or the one-hot), and behind the global average pool every position of a
+ * channel has that gradient / HW -> cam [n, HW] = relu(sum_c w_c act_c), shifted by the global minimum and divided by the global
+ * maximum as the reference does.  state: 2 floats of scratch. */
+int mst_gradcampp(const float* act, const float* out, int O, const float* W, int n, int HW, int C, float* cam, float* state,
+                  mst_stream_t stream);
 
 /* Input pipeline in front of the model (reference mst/data/datasets/augmentations/augmentations_3d.py on
  * torchio 0.19.9, which is not part of the reference tree: restated from its published algorithm, numpy.pad semantics included).

@@ -234,6 +234,45 @@ int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_
     return launch_avgpool_nhwc(x, n, HW, C, y, (hipStream_t)stream);
 }
 
+int mst_batchnorm_train(const float* z, int64_t rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                        const float* residual, int relu, float* y, float* mean, float* rstd, float* running_mean,
+                        float* running_var, float* scratch, mst_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MST_CHECK_ARG(z && gamma && beta && y && mean && rstd && scratch && rows > 0 && C > 0, "batchnorm_train: bad arguments");
+    if (hipMemsetAsync(scratch, 0, sizeof(float) * C, s) != hipSuccess) { mst_set_error("batchnorm_train: memset failed"); return MST_ELAUNCH; }
+    int rc = launch_colsum(z, C, nullptr, 0, rows, C, scratch, s);
+    if (rc) return rc;
+    if ((rc = launch_bn_finalize(0, scratch, rows, C, eps, momentum, mean, rstd, nullptr, nullptr, s))) return rc;
+    if (hipMemsetAsync(scratch, 0, sizeof(float) * C, s) != hipSuccess) { mst_set_error("batchnorm_train: memset failed"); return MST_ELAUNCH; }
+    if ((rc = launch_colsqdev(z, mean, rows, C, scratch, s))) return rc;
+    if ((rc = launch_bn_finalize(1, scratch, rows, C, eps, momentum, mean, rstd, running_mean, running_var, s))) return rc;
+    return launch_bn_apply(z, mean, rstd, gamma, beta, residual, relu, rows, C, y, s);
+}
+int mst_batchnorm_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* dy, int64_t rows, int C,
+                      float* dgamma, float* dbeta, float* dz, mst_stream_t stream) {
+    MST_CHECK_ARG(z && mean && rstd && gamma && dy && dgamma && dbeta && dz && rows > 0 && C > 0, "batchnorm_bwd: bad arguments");
+    return launch_bn_bwd(z, mean, rstd, gamma, dy, rows, C, dgamma, dbeta, dz, (hipStream_t)stream);
+}
+int mst_col2im_nhwc(const float* dcol, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* dx,
+                    mst_stream_t stream) {
+    MST_CHECK_ARG(dcol && dx && n > 0 && H > 0 && W > 0 && C > 0, "col2im_nhwc: bad arguments");
+    return launch_col2im_nhwc(dcol, n, H, W, C, kh, kw, stride, pad, Kpad, dx, (hipStream_t)stream);
+}
+int mst_maxpool_bwd_nhwc(const float* x, const float* dy, int n, int H, int W, int C, float* dx, mst_stream_t stream) {
+    MST_CHECK_ARG(x && dy && dx && n > 0, "maxpool_bwd_nhwc: bad arguments");
+    return launch_maxpool_bwd_nhwc(x, dy, n, H, W, C, dx, (hipStream_t)stream);
+}
+int mst_avgpool_bwd_nhwc(const float* dy, int n, int HW, int C, float* dx, mst_stream_t stream) {
+    MST_CHECK_ARG(dy && dx && n > 0 && HW > 0 && C > 0, "avgpool_bwd_nhwc: bad arguments");
+    return launch_avgpool_bwd_nhwc(dy, n, HW, C, dx, (hipStream_t)stream);
+}
+
+int mst_gradcampp(const float* act, const float* out, int O, const float* W, int n, int HW, int C, float* cam, float* state,
+                  mst_stream_t stream) {
+    MST_CHECK_ARG(act && out && cam && state && n > 0 && HW > 0 && C > 0 && C <= 8192 && O > 0 && (W || O == C), "gradcampp: bad arguments");
+    return launch_gradcampp(act, out, O, W, n, HW, C, cam, state, (hipStream_t)stream);
+}
+
 // ---- input pipeline ------------------------------------------------------------------------------------
 int mst_crop_or_pad(const float* src, int s0, int s1, int s2, float* dst, int t0, int t1, int t2, int pad_minimum,
                     float pad_value, void* ws, size_t ws_bytes, mst_stream_t stream) {

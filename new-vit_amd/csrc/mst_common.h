@@ -226,6 +226,19 @@ int launch_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int k
                        hipStream_t s);
 int launch_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, hipStream_t s);
 int launch_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, hipStream_t s);
+int launch_colsqdev(const float* z, const float* mean, int64_t rows, int C, float* out, hipStream_t s);
+int launch_bn_finalize(int stage, const float* acc, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
+                       float* running_mean, float* running_var, hipStream_t s);
+int launch_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* res,
+                    int relu, int64_t rows, int C, float* y, hipStream_t s);
+int launch_bn_bwd(const float* z, const float* mean, const float* rstd, const float* gamma, const float* dy, int64_t rows, int C,
+                  float* dgamma, float* dbeta, float* dz, hipStream_t s);
+int launch_col2im_nhwc(const float* dcol, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* dx,
+                       hipStream_t s);
+int launch_maxpool_bwd_nhwc(const float* x, const float* dy, int n, int H, int W, int C, float* dx, hipStream_t s);
+int launch_avgpool_bwd_nhwc(const float* dy, int n, int HW, int C, float* dx, hipStream_t s);
+int launch_gradcampp(const float* act, const float* out, int O, const float* W, int n, int HW, int C, float* cam, float* state,
+                     hipStream_t s);
 size_t znorm_state_bytes(void);
 int launch_pad_axis(float* v, int n0, int n1, int n2, int axis, int lo, int hi, int a0, int a1, int b0, int b1, int use_const,
                     float cval, hipStream_t s);

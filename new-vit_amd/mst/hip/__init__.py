@@ -83,6 +83,12 @@ SIGNATURES = {
     "mst_im2col_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mst_batchnorm_train": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mst_batchnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "mst_col2im_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_maxpool_bwd_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mst_avgpool_bwd_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mst_gradcampp": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mst_crop_or_pad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "mst_znorm_state_bytes": (_sz, []),
     "mst_znorm": (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
@@ -554,6 +560,63 @@ def avgpool_nhwc(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((n, Cc), dtype=torch.float32, device=x.device)
     _check(load().mst_avgpool_nhwc(ptr(x), n, H * W, Cc, ptr(y), stream_of(x)), "mst_avgpool_nhwc")
     return y
+
+
+def batchnorm_train(z: torch.Tensor, bn, residual: Optional[torch.Tensor], relu: bool, momentum: float = 0.1):
+    """nn.BatchNorm2d in train mode on z [rows, C] (+ residual, ReLU): returns (y, mean, rstd); updates bn.running_* in place."""
+    _dev(z, "batchnorm_train")
+    rows, Cc = z.shape
+    dev = z.device
+    y = torch.empty_like(z)
+    mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+    scratch = torch.empty(Cc, dtype=torch.float32, device=dev)
+    _check(load().mst_batchnorm_train(ptr(z), rows, Cc, ptr(bn.weight.detach()), ptr(bn.bias.detach()), bn.eps, momentum, ptr(residual),
+                                      1 if relu else 0, ptr(y), ptr(mean), ptr(rstd), ptr(bn.running_mean), ptr(bn.running_var),
+                                      ptr(scratch), stream_of(z)), "mst_batchnorm_train")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(z: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor):
+    """Returns (dz, dgamma, dbeta)."""
+    rows, Cc = z.shape
+    dg = torch.zeros(Cc, dtype=torch.float32, device=z.device)
+    db = torch.zeros(Cc, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    _check(load().mst_batchnorm_bwd(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dy), rows, Cc, ptr(dg), ptr(db), ptr(dz),
+                                    stream_of(z)), "mst_batchnorm_bwd")
+    return dz, dg, db
+
+
+def col2im_nhwc(dcol: torch.Tensor, dx: torch.Tensor, kh: int, kw: int, stride: int, pad: int):
+    """dx [n,H,W,C] += adjoint of im2col_nhwc applied to dcol [n*Ho*Wo, Kpad]."""
+    n, H, W, Cc = dx.shape
+    _check(load().mst_col2im_nhwc(ptr(dcol), n, H, W, Cc, kh, kw, stride, pad, dcol.shape[1], ptr(dx), stream_of(dx)), "mst_col2im_nhwc")
+    return dx
+
+
+def maxpool_bwd_nhwc(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    n, H, W, Cc = x.shape
+    dx = torch.zeros_like(x)
+    _check(load().mst_maxpool_bwd_nhwc(ptr(x), ptr(dy), n, H, W, Cc, ptr(dx), stream_of(x)), "mst_maxpool_bwd_nhwc")
+    return dx
+
+
+def avgpool_bwd_nhwc(dy: torch.Tensor, HW: int) -> torch.Tensor:
+    n, Cc = dy.shape
+    dx = torch.empty((n, HW, Cc), dtype=torch.float32, device=dy.device)
+    _check(load().mst_avgpool_bwd_nhwc(ptr(dy), n, HW, Cc, ptr(dx), stream_of(dy)), "mst_avgpool_bwd_nhwc")
+    return dx
+
+
+def gradcampp(act: torch.Tensor, out: torch.Tensor, fc_weight: Optional[torch.Tensor]) -> torch.Tensor:
+    """Grad-CAM++ map of the last ReLU output: act [n, HW, C], out [n, O] model output, fc_weight [O, C] or None -> [n, HW]."""
+    n, HW, Cc = act.shape
+    cam = torch.empty((n, HW), dtype=torch.float32, device=act.device)
+    state = torch.empty(2, dtype=torch.float32, device=act.device)
+    _check(load().mst_gradcampp(ptr(act), ptr(out), out.shape[1], ptr(fc_weight), n, HW, Cc, ptr(cam), ptr(state), stream_of(act)),
+           "mst_gradcampp")
+    return cam
 
 
 class Profiler:

@@ -16,9 +16,13 @@ torchvision's source is not part of the reference tree: the pub
 the backbone is against ``oracle/resnet_oracle.py`` (plain torch ops) and therefore UNPINNED; the fusion half is pinned by a
 fixture of the reference's own ``TransformerEncoderLayer`` (tests/golden/resnet_fusion.npz).
 
-Not built (raise): the training step of the backbone (BatchNorm batch statistics, convolution backward) and with it Grad-CAM++
-(``save_attn`` on the backbone, resnet.py:62-122), the MONAI branches (3-D, and ``pretrained=False`` in the reference), bottleneck
-ResNets (model >= 50).  ``pretrained=True`` needs torchvision's weights (network / hub cache); when torchvision is absent the tree
+  training   with gradients enabled in train mode the output carries one autograd node (mst/train_resnet.py): BatchNorm with batch
+             statistics, convolution / pooling / slice-transformer backward in HIP kernels (BASELINE configs[3]'s step).
+  Grad-CAM++ ``save_attn=True`` (resnet.py:62-118): the map of the LAST ReLU output -- the one ``get_attention_maps`` returns --
+             by ``mst_gradcampp``; the maps of the earlier ReLUs, which the reference computes and never exposes, are not produced.
+
+Not built (raise): the MONAI branches (3-D, and ``pretrained=False`` in the reference), bottleneck ResNets (model >= 50), a
+backward pass through eval-mode BatchNorm (gradients with ``model.eval()``).  ``pretrained=True`` needs torchvision's weights (network / hub cache); when torchvision is absent the tree
 is initialised like torchvision's and a warning says so -- a checkpoint's ``state_dict`` replaces it anyway.
 """
 from __future__ import annotations
@@ -168,10 +172,12 @@ class ResNet(BasicClassifier):
         self._prep = prep
         return prep
 
-    def _features(self, x_nhwc: torch.Tensor, sum_in: bool) -> torch.Tensor:
-        """[n, H, W, C] fp32 on the device -> [n, 512] (avgpool output, before fc)."""
+    def _features(self, x_nhwc: torch.Tensor, sum_in: bool, keep_last: bool = False) -> torch.Tensor:
+        """[n, H, W, C] fp32 on the device -> [n, 512] (avgpool output, before fc).  keep_last: the last ReLU output of every image
+        stays in ``self._last_act`` [n, h*w, 512] for Grad-CAM++."""
         p = self._prepare(sum_in)
         outs: List[torch.Tensor] = []
+        lasts: List[torch.Tensor] = []
         for i0 in range(0, x_nhwc.shape[0], self.chunk_images):
             x = x_nhwc[i0:i0 + self.chunk_images].contiguous()
             n, H, W, _ = x.shape
@@ -195,31 +201,52 @@ class ResNet(BasicClassifier):
                 hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))          # ReLU in place
                 y = idt.view(n, Ho, Wo, w2.shape[0])
             outs.append(hip.avgpool_nhwc(y))
+            if keep_last:
+                lasts.append(y)
+        if keep_last:
+            y = torch.cat(lasts, dim=0) if len(lasts) > 1 else lasts[0]
+            self._last_hw = (y.shape[1], y.shape[2])
+            self._last_act = y.view(y.shape[0], -1, y.shape[3])
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
+    def _wants_grad(self) -> bool:
+        if not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters()):
+            return False
+        if not self.training:
+            raise NotImplementedError("ResNet: gradients through eval-mode BatchNorm are not on the HIP path; call .train() for a "
+                                      "training step or run the forward under torch.no_grad()")
+        return True
+
+    def _gradcam(self, out: torch.Tensor, fc_weight: Optional[torch.Tensor]):
+        """resnet.py:66-70 + 93-118 for the last ReLU: attention_maps[-1] = [N, 1, h, w]."""
+        h, w = self._last_hw
+        cam = hip.gradcampp(self._last_act, out.detach().contiguous(), fc_weight)
+        self.attention_maps = [cam.view(-1, 1, h, w)]
+        self._last_act = None
+
     def forward(self, source, save_attn=False, **kwargs):
-        if save_attn:
-            raise NotImplementedError("ResNet(save_attn=True): Grad-CAM++ (resnet.py:62-122) needs the backbone's backward pass, "
-                                      "which is not on the HIP path yet (SURVEY.md 8f-2)")
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("ResNet: the training step of the convolutional backbone (BatchNorm batch statistics, "
-                                      "convolution backward) is not on the HIP path yet; run the forward under torch.no_grad() / eval()")
         x = source.to(self.device)                       # [N, C, H, W]
         if x.dim() != 4:
             raise RuntimeError(f"Expected 4D input [N, C, H, W] to the 2-D resnet, got {tuple(x.shape)}")
         if x.shape[1] != 3:
             raise RuntimeError(f"Given groups=1, weight of size [64, 3, 7, 7], expected input{list(x.shape)} to have 3 channels, "
                                f"but got {x.shape[1]} channels instead")
-        feat = self._features(x.float().permute(0, 2, 3, 1).contiguous(), False)
+        x = x.float().permute(0, 2, 3, 1).contiguous()
+        if self._wants_grad():
+            if save_attn:
+                raise NotImplementedError("ResNet: save_attn inside a training forward is not supported; compute the maps under "
+                                          "torch.no_grad()")
+            from .. import train_resnet
+            return train_resnet.forward_with_grad(self, x, False)
+        feat = self._features(x, False, keep_last=save_attn)
         p = self._prep
-        if "fc" in p:
-            return hip.gemm(feat, p["fc"][0], p["fc"][1], epilogue=hip.EPI_BIAS)
-        return feat
+        out = hip.gemm(feat, p["fc"][0], p["fc"][1], epilogue=hip.EPI_BIAS) if "fc" in p else feat
+        if save_attn:
+            self._gradcam(out, p["fc"][0] if "fc" in p else None)
+        return out
 
     def get_attention_maps(self):
-        if not self.attention_maps:
-            raise NotImplementedError("Grad-CAM++ attention maps need the backbone's backward pass (not on the HIP path yet)")
-        return self.attention_maps[-1]
+        return self.attention_maps[-1]                   # [N, 1, h, w]  (resnet.py:75-76)
 
 
 SLICE_HEADS = 16      # reference resnet.py:151
@@ -321,16 +348,22 @@ class ResNetSliceTrans(ResNet):
 
     def forward(self, source, src_key_padding_mask=None, **kwargs):
         save_attn = bool(kwargs.get("save_attn"))
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("ResNetSliceTrans: the training step (BASELINE configs[3]) needs the backbone's backward pass, "
-                                      "which is not on the HIP path yet (SURVEY.md 8f-2); inference runs under torch.no_grad() / eval()")
         x = source.to(self.device)                       # [B, C, D, H, W]
         B, C, D, H, W = x.shape
         if C != 1:                                       # x.repeat(1, 3, ...) then a 3-channel conv1: only gray volumes fit (resnet.py:176)
             raise RuntimeError(f"Given groups=1, weight of size [64, 3, 7, 7], expected input[{B * D}, {3 * C}, {H}, {W}] to have 3 "
                                f"channels, but got {3 * C} channels instead")
         self._last_shape = (B, D)
-        emb = self._features(x.float().reshape(B * D, H, W, 1).contiguous(), True)      # 'b c d h w -> (b d) c h w', gray -> RGB folded
+        x = x.float().reshape(B * D, H, W, 1).contiguous()                              # 'b c d h w -> (b d) c h w', gray -> RGB folded
+        if self._wants_grad():
+            if save_attn:
+                raise NotImplementedError("ResNetSliceTrans: save_attn inside a training forward is not supported; compute the maps "
+                                          "under torch.no_grad()")
+            from .. import train_resnet
+            return train_resnet.forward_with_grad(self, x, True, B, D, src_key_padding_mask)
+        emb = self._features(x, True, keep_last=save_attn)
+        if save_attn:
+            self._gradcam(emb, None)                     # super().forward(x, save_attn=True) with fc = Identity (resnet.py:181)
         return self.fuse(emb, B, D, src_key_padding_mask, save_attn)
 
     def get_slice_attention(self):
@@ -339,3 +372,6 @@ class ResNetSliceTrans(ResNet):
         out = torch.empty((B * D,), dtype=torch.float32, device=sp.device)
         hip.attention_readout(None, sp, B, D, 1, 2, 0, SLICE_HEADS, None, out, None)
         return out[:, None, None]                        # [B*D, 1, 1]  (resnet.py:196-205)
+
+    def get_attention_maps(self):
+        return self.get_slice_attention().unsqueeze(-1) * super().get_attention_maps()      # [B*D, 1, h, w]  (resnet.py:207-212)

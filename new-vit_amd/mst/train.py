@@ -99,6 +99,65 @@ def _attention_bwd(dout: torch.Tensor, qkv: torch.Tensor, P: torch.Tensor, nb: i
     return dqkv
 
 
+def fusion_fwd(model, tok: torch.Tensor, B: int, D: int, e: int, hs: int, mask: Optional[torch.Tensor]):
+    """Slice Transformer (one pre-norm nn.TransformerEncoderLayer with ReLU + final LayerNorm; dino.py:134-153, resnet.py:180-190)
+    over [CLS | D slice tokens] per volume; `model` carries slice_fusion.layers[0], slice_fusion.norm and cls_token.  Returns the
+    CLS features [B, e] and what the backward needs."""
+    dev = tok.device
+    lay = model.slice_fusion.layers[0]
+    L = D + 1
+    hd = e // hs
+    xs = torch.cat([model.cls_token.detach().expand(B, 1, e), tok.view(B, D, e)], dim=1).contiguous().view(B * L, e)
+    mk = None
+    if mask is not None:
+        mk = torch.cat([torch.zeros((B, 1), dtype=torch.uint8, device=dev), mask.to(dev).to(torch.uint8)], dim=1).contiguous()
+    t = {"xs": xs, "mask": mk}
+    t["y1"] = hip.layernorm(xs, lay.norm1.weight.detach(), lay.norm1.bias.detach(), 1e-5)
+    t["qkv"] = hip.gemm(t["y1"], lay.self_attn.in_proj_weight.detach(), lay.self_attn.in_proj_bias.detach())
+    t["ao"], t["P"] = _attention_fwd(t["qkv"], B, L, hs, hd, 1.0 / math.sqrt(hd), mk)
+    xs1 = xs.clone()
+    hip.axpby_cols(_lin_fwd(t["ao"], lay.self_attn.out_proj), xs1)
+    t["xs1"] = xs1
+    t["y2"] = hip.layernorm(xs1, lay.norm2.weight.detach(), lay.norm2.bias.detach(), 1e-5)
+    t["f1"] = _lin_fwd(t["y2"], lay.linear1)
+    t["r"] = hip.act_fwd(t["f1"], 1)
+    xs2 = xs1.clone()
+    hip.axpby_cols(_lin_fwd(t["r"], lay.linear2), xs2)
+    t["xs2"] = xs2
+    feat = hip.layernorm_rows(xs2, L * e, B, e, model.slice_fusion.norm.weight.detach(), model.slice_fusion.norm.bias.detach(), 1e-5)
+    return feat, t
+
+
+def fusion_bwd(G: "_Grads", model, t, dfeat: torch.Tensor, B: int, D: int, e: int, hs: int) -> torch.Tensor:
+    """Backward of `fusion_fwd`: parameter gradients into G, returns the gradient of the slice tokens [B*D, e]."""
+    dev = dfeat.device
+    lay = model.slice_fusion.layers[0]
+    L = D + 1
+    hd = e // hs
+    dxs2 = torch.zeros((B * L, e), dtype=torch.float32, device=dev)
+    G.ln_bwd(t["xs2"], L * e, model.slice_fusion.norm, dfeat, e, None, 0, dxs2, L * e, B, e, 1e-5)      # row 0 of every volume
+    dr = G.lin_bwd(dxs2, t["r"], lay.linear2)
+    hip.act_bwd(t["f1"], dr, 1)
+    dy2 = G.lin_bwd(dr, t["y2"], lay.linear1)
+    dxs1 = torch.empty_like(dxs2)
+    G.ln_bwd(t["xs1"], e, lay.norm2, dy2, e, dxs2, e, dxs1, e, B * L, e, 1e-5)
+    dao = G.lin_bwd(dxs1, t["ao"], lay.self_attn.out_proj)
+    dqkv = _attention_bwd(dao, t["qkv"], t["P"], B, L, hs, hd, 1.0 / math.sqrt(hd), 1.0)
+    sa = lay.self_attn
+    dW = torch.empty_like(sa.in_proj_weight)
+    hip.gemm_ex(dqkv, t["y1"], dW, 3 * e, e, B * L, sa=(1, 3 * e), sb=(e, 1), sc=(e, 1))
+    G.put(sa.in_proj_weight, dW)
+    G.put(sa.in_proj_bias, hip.colsum(dqkv, torch.zeros(3 * e, dtype=torch.float32, device=dev)))
+    dy1 = torch.empty((B * L, e), dtype=torch.float32, device=dev)
+    hip.gemm_ex(dqkv, sa.in_proj_weight.detach(), dy1, B * L, e, 3 * e, sa=(3 * e, 1), sb=(e, 1), sc=(e, 1))
+    dxs = torch.empty_like(dxs2)
+    G.ln_bwd(t["xs"], e, lay.norm1, dy1, e, dxs1, e, dxs, e, B * L, e, 1e-5)
+    dcls = torch.zeros(e, dtype=torch.float32, device=dev)
+    hip._check(hip.load().mst_colsum(hip.ptr(dxs), L * e, None, 0, B, e, hip.ptr(dcls), hip.stream_of(dxs)), "mst_colsum")
+    G.put(model.cls_token, dcls)
+    return dxs.view(B, L, e)[:, 1:].contiguous().view(B * D, e)
+
+
 def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], without_linear: bool):
     import torch.nn as nn
     if model.rotary is not None:
@@ -168,28 +227,7 @@ def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], wit
             hip.axpby_cols(p, tok[b * D:(b + 1) * D])
     ft = model.slice_fusion_type
     if ft == "transformer":
-        lay = model.slice_fusion.layers[0]
-        L = D + 1
-        hs, hd = 12, e // 12
-        xs = torch.cat([model.cls_token.detach().expand(B, 1, e), tok.view(B, D, e)], dim=1).contiguous().view(B * L, e)
-        mk = None
-        if mask is not None:
-            mk = torch.cat([torch.zeros((B, 1), dtype=torch.uint8, device=dev), mask.to(dev).to(torch.uint8)], dim=1).contiguous()
-        t = {"xs": xs, "mask": mk}
-        t["y1"] = hip.layernorm(xs, lay.norm1.weight.detach(), lay.norm1.bias.detach(), 1e-5)
-        t["qkv"] = hip.gemm(t["y1"], lay.self_attn.in_proj_weight.detach(), lay.self_attn.in_proj_bias.detach())
-        t["ao"], t["P"] = _attention_fwd(t["qkv"], B, L, hs, hd, 1.0 / math.sqrt(hd), mk)
-        xs1 = xs.clone()
-        hip.axpby_cols(_lin_fwd(t["ao"], lay.self_attn.out_proj), xs1)
-        t["xs1"] = xs1
-        t["y2"] = hip.layernorm(xs1, lay.norm2.weight.detach(), lay.norm2.bias.detach(), 1e-5)
-        t["f1"] = _lin_fwd(t["y2"], lay.linear1)
-        t["r"] = hip.act_fwd(t["f1"], 1)
-        xs2 = xs1.clone()
-        hip.axpby_cols(_lin_fwd(t["r"], lay.linear2), xs2)
-        t["xs2"] = xs2
-        feat = hip.layernorm_rows(xs2, L * e, B, e, model.slice_fusion.norm.weight.detach(), model.slice_fusion.norm.bias.detach(), 1e-5)
-        sv["fusion"] = t
+        feat, sv["fusion"] = fusion_fwd(model, tok, B, D, e, 12, mask)
     elif ft == "linear":
         feat = tok.reshape(B, D * e)
     else:                                                                        # 'average' (dino.py:156-157)
@@ -217,32 +255,7 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
     dfeat = G.lin_bwd(dout, sv["feat"], model.linear) if sv["head"] else dout
     ft = model.slice_fusion_type
     if ft == "transformer":
-        t = sv["fusion"]
-        lay = model.slice_fusion.layers[0]
-        L = D + 1
-        hs, hd = 12, e // 12
-        dxs2 = torch.zeros((B * L, e), dtype=torch.float32, device=dev)
-        G.ln_bwd(t["xs2"], L * e, model.slice_fusion.norm, dfeat, e, None, 0, dxs2, L * e, B, e, 1e-5)      # row 0 of every volume
-        dr = G.lin_bwd(dxs2, t["r"], lay.linear2)
-        hip.act_bwd(t["f1"], dr, 1)
-        dy2 = G.lin_bwd(dr, t["y2"], lay.linear1)
-        dxs1 = torch.empty_like(dxs2)
-        G.ln_bwd(t["xs1"], e, lay.norm2, dy2, e, dxs2, e, dxs1, e, B * L, e, 1e-5)
-        dao = G.lin_bwd(dxs1, t["ao"], lay.self_attn.out_proj)
-        dqkv = _attention_bwd(dao, t["qkv"], t["P"], B, L, hs, hd, 1.0 / math.sqrt(hd), 1.0)
-        sa = lay.self_attn
-        dW = torch.empty_like(sa.in_proj_weight)
-        hip.gemm_ex(dqkv, t["y1"], dW, 3 * e, e, B * L, sa=(1, 3 * e), sb=(e, 1), sc=(e, 1))
-        G.put(sa.in_proj_weight, dW)
-        G.put(sa.in_proj_bias, hip.colsum(dqkv, torch.zeros(3 * e, dtype=torch.float32, device=dev)))
-        dy1 = torch.empty((B * L, e), dtype=torch.float32, device=dev)
-        hip.gemm_ex(dqkv, sa.in_proj_weight.detach(), dy1, B * L, e, 3 * e, sa=(3 * e, 1), sb=(e, 1), sc=(e, 1))
-        dxs = torch.empty_like(dxs2)
-        G.ln_bwd(t["xs"], e, lay.norm1, dy1, e, dxs1, e, dxs, e, B * L, e, 1e-5)
-        dcls = torch.zeros(e, dtype=torch.float32, device=dev)
-        hip._check(hip.load().mst_colsum(hip.ptr(dxs), L * e, None, 0, B, e, hip.ptr(dcls), hip.stream_of(dxs)), "mst_colsum")
-        G.put(model.cls_token, dcls)
-        dtok = dxs.view(B, L, e)[:, 1:].contiguous().view(B * D, e)
+        dtok = fusion_bwd(G, model, sv["fusion"], dfeat, B, D, e, 12)
     elif ft == "linear":
         dtok = dfeat.reshape(B * D, e).contiguous()
     else:

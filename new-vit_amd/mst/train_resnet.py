@@ -1,0 +1,194 @@
+"""Training step of ResNet / ResNetSliceTrans on the HIP path (BASELINE configs[3]).
+
+The reference trains these through torch.autograd over torchvision's modules (mst/models/base_model.py:148-181 `_step`,
+mst/models/resnet.py:172-193).  Here, as for DinoV2ClassifierSlice (mst/train.py), the logits carry ONE autograd node whose
+forward runs the model op by op through the C ABI and whose backward produces every parameter gradient with HIP kernels:
+
+  convolution      z = im2col(x) . Wg^T             (mst_im2col_nhwc + mst_gemm, exact fp32 MFMA; Wg = weight in (ky, kx, c) order)
+     backward      dWg = dz^T . im2col(x) (split over images, partial sums reduced by mst_colsum), dx = col2im(dz . Wg)
+  BatchNorm2d      batch statistics + running-stat update (mst_batchnorm_train), residual add and ReLU in the same pass
+     backward      mst_batchnorm_bwd (ReLU mask first: mst_act_bwd on the saved output)
+  max / avg pool   mst_maxpool_bwd_nhwc / mst_avgpool_bwd_nhwc
+  slice fusion     mst.train.fusion_fwd / fusion_bwd with 16 heads over 512-wide tokens
+
+BatchNorm in train mode normalises over ALL (B D) images of the step, so the step is not chunked: activations of the whole batch stay
+resident (fp32 NHWC; about 60 MB per 224^2 image for resnet34 -- sized for 288 GB of HBM).  The im2col matrix is rebuilt in the
+backward instead of being kept.  Checked against torch.autograd of oracle/resnet_oracle.py on every parameter
+(tests/test_resnet_gpu.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .train import _Grads, fusion_bwd, fusion_fwd
+
+
+def _gemm_weight(conv, sum_in: bool) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> [Cout, Kpad] in (ky, kx, c) order (identical input channels summed when the gray volume was repeated)."""
+    w = conv.weight.detach()
+    if sum_in:
+        w = w.sum(dim=1, keepdim=True)
+    w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    K = w.shape[1]
+    kpad = (K + 15) // 16 * 16
+    if kpad != K:
+        w = torch.cat([w, w.new_zeros(w.shape[0], kpad - K)], dim=1)
+    return w.contiguous()
+
+
+def _conv_bn_fwd(x: torch.Tensor, conv, bn, k: int, stride: int, pad: int, sum_in: bool, residual: Optional[torch.Tensor],
+                 relu: bool):
+    """x [n,H,W,C] -> y [n,Ho,Wo,Cout] plus the record the backward needs."""
+    n, H, W, _ = x.shape
+    wg = _gemm_weight(conv, sum_in)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    z = hip.gemm(hip.im2col_nhwc(x, k, k, stride, pad, wg.shape[1]), wg, None, epilogue=hip.EPI_BIAS)
+    y, mean, rstd = hip.batchnorm_train(z, bn, residual, relu)
+    bn.num_batches_tracked += 1
+    rec = {"x": x, "z": z, "y": y if relu else None, "mean": mean, "rstd": rstd, "wg": wg, "k": k, "stride": stride, "pad": pad,
+           "sum_in": sum_in, "relu": relu, "conv": conv, "bn": bn}
+    return y.view(n, Ho, Wo, wg.shape[0]), rec
+
+
+def _split(n: int, hw: int):
+    """Split the rows of one layer's im2col matrix for dW: (images, parts per image) with parts | hw, about 256 partial products."""
+    s2 = 1
+    while s2 < 16 and hw % (s2 * 2) == 0 and n * s2 < 256:
+        s2 *= 2
+    return n, s2
+
+
+def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
+    """dy [rows, Cout] = gradient of the unit's output (modified in place by the ReLU mask).  Returns dx [n,H,W,C] or None.  The
+    caller routes the masked dy to the residual branch itself."""
+    x, z, wg = rec["x"], rec["z"], rec["wg"]
+    conv, bn = rec["conv"], rec["bn"]
+    k, stride, pad = rec["k"], rec["stride"], rec["pad"]
+    n, H, W, Cin = x.shape
+    rows, Cout = z.shape
+    kpad = wg.shape[1]
+    dev = z.device
+    if rec["relu"]:
+        hip.act_bwd(rec["y"], dy, 1)
+    dz, dg, db = hip.batchnorm_bwd(z, rec["mean"], rec["rstd"], bn.weight.detach(), dy)
+    G.put(bn.weight, dg)
+    G.put(bn.bias, db)
+    col = hip.im2col_nhwc(x, k, k, stride, pad, kpad)
+    hw = rows // n
+    s1, s2 = _split(n, hw)
+    part = torch.empty((s1 * s2, Cout * kpad), dtype=torch.float32, device=dev)
+    ch = hw // s2                                                        # rows per partial product
+    hip.gemm_ex(dz, col, part, Cout, kpad, ch, sa=(1, Cout), sb=(kpad, 1), sc=(kpad, 1), nb=(s1, s2), ba=(hw * Cout, ch * Cout),
+                bb=(hw * kpad, ch * kpad), bc=(s2 * Cout * kpad, Cout * kpad))
+    dwg = hip.colsum(part, torch.zeros(Cout * kpad, dtype=torch.float32, device=dev)).view(Cout, kpad)
+    K = k * k * Cin
+    dw = dwg[:, :K].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    if rec["sum_in"]:
+        dw = dw.expand(Cout, conv.weight.shape[1], k, k)                  # w_eff = sum over the identical input channels
+    G.put(conv.weight, dw.contiguous())
+    if not need_dx:
+        return None
+    hip.gemm_ex(dz, wg, col, rows, kpad, Cout, sa=(Cout, 1), sb=(kpad, 1), sc=(kpad, 1))      # dcol overwrites col
+    dx = torch.zeros_like(x)
+    return hip.col2im_nhwc(col, dx, k, k, stride, pad)
+
+
+def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool):
+    """torchvision resnet{18,34} forward in train mode up to the pooled features [n, 512]."""
+    sv = {"units": []}
+    y, sv["stem"] = _conv_bn_fwd(x_nhwc.contiguous(), m.conv1, m.bn1, 7, 2, 3, sum_in, None, True)
+    sv["pool_in"] = y
+    y = hip.maxpool_nhwc(y)
+    for li in range(4):
+        for blk in getattr(m, f"layer{li + 1}"):
+            n, H, W, Cin = y.shape
+            h1, r1 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 3, blk.stride, 1, False, None, True)
+            rd = None
+            if hasattr(blk, "downsample"):
+                idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False)
+                idt = idt.reshape(-1, idt.shape[-1])
+            else:
+                idt = y.reshape(n * H * W, Cin)
+            y, r2 = _conv_bn_fwd(h1, blk.conv2, blk.bn2, 3, 1, 1, False, idt, True)
+            sv["units"].append((r1, r2, rd))
+    sv["last"] = y
+    return hip.avgpool_nhwc(y), sv
+
+
+def backbone_bwd(G: _Grads, sv, dfeat: torch.Tensor):
+    y = sv["last"]
+    n, H, W, Cc = y.shape
+    dy = hip.avgpool_bwd_nhwc(dfeat.contiguous(), H * W).view(n * H * W, Cc)
+    for r1, r2, rd in reversed(sv["units"]):
+        dh1 = _conv_bn_bwd(G, r2, dy, True)                               # dy now carries the ReLU mask of the block output
+        xin = r1["x"]
+        if rd is not None:
+            dx = _conv_bn_bwd(G, rd, dy.clone(), True)
+        else:
+            dx = dy.view(xin.shape).clone()
+        d1 = _conv_bn_bwd(G, r1, dh1.view(-1, dh1.shape[-1]), True)
+        hip.axpby_cols(d1.view(1, -1), dx.view(1, -1))
+        dy = dx.view(-1, dx.shape[-1])
+    dstem = hip.maxpool_bwd_nhwc(sv["pool_in"], dy.view(sv["units"][0][0]["x"].shape))
+    _conv_bn_bwd(G, sv["stem"], dstem.view(-1, dstem.shape[-1]), False)
+
+
+# ---- whole models ------------------------------------------------------------------------------------------------------
+def forward_train(model, x_nhwc: torch.Tensor, sum_in: bool, B: Optional[int], D: Optional[int], mask: Optional[torch.Tensor]):
+    """B/D given: ResNetSliceTrans (features -> slice transformer -> linear); else plain ResNet (features -> fc)."""
+    feat, sv = backbone_fwd(model.model, x_nhwc, sum_in)
+    sv["feat"] = feat
+    if B is None:
+        fc = model.model.fc
+        if isinstance(fc, nn.Identity):
+            return feat, sv
+        return hip.gemm(feat, fc.weight.detach(), fc.bias.detach()), sv
+    from .models.resnet import SLICE_HEADS
+    e = model.emb_ch
+    fused, sv["fusion"] = fusion_fwd(model, feat, B, D, e, SLICE_HEADS, mask)
+    sv["fused"], sv["B"], sv["D"] = fused, B, D
+    return hip.gemm(fused, model.linear.weight.detach(), model.linear.bias.detach()), sv
+
+
+def backward_train(model, sv, dout: torch.Tensor):
+    G = _Grads()
+    if "fusion" in sv:
+        from .models.resnet import SLICE_HEADS
+        dfused = G.lin_bwd(dout, sv["fused"], model.linear)
+        dfeat = fusion_bwd(G, model, sv["fusion"], dfused, sv["B"], sv["D"], model.emb_ch, SLICE_HEADS)
+    else:
+        fc = model.model.fc
+        dfeat = dout if isinstance(fc, nn.Identity) else G.lin_bwd(dout, sv["feat"], fc)
+    backbone_bwd(G, sv, dfeat)
+    return G.by_param
+
+
+class _ResNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x_nhwc, sum_in, B, D, mask, *params):
+        with torch.no_grad():
+            out, saved = forward_train(model, x_nhwc, sum_in, B, D, mask)
+        ctx.model, ctx.saved, ctx.params = model, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.no_grad():
+            grads = backward_train(ctx.model, ctx.saved, dout.contiguous().float())
+        ctx.saved = None
+        out: List[Optional[torch.Tensor]] = []
+        for p, need in zip(ctx.params, ctx.needs_input_grad[6:]):
+            out.append(grads.get(id(p)) if need else None)
+        return (None, None, None, None, None, None, *out)
+
+
+def forward_with_grad(model, x_nhwc, sum_in: bool, B=None, D=None, mask=None):
+    params = [p for p in model.parameters()]
+    for p in params:
+        if p.dtype != torch.float32 or p.device.type != "cuda":
+            raise RuntimeError("training step: parameters must be fp32 on the MI355X (model.float().cuda()); there is no CPU fallback")
+    return _ResNetFunction.apply(model, x_nhwc, sum_in, B, D, mask, *params)

@@ -24,7 +24,7 @@ def _oracle_grads(name, kw, seed, src, mask, target, without_linear=False):
     y = out["features"] if without_linear else out["logits"]
     loss = y.square().sum() if without_linear else torch.nn.functional.cross_entropy(y, target)
     loss.backward()
-    return float(loss), {k: v.grad for k, v in sd.items()}, y.detach()
+    return float(loss.detach()), {k: v.grad for k, v in sd.items()}, y.detach()
 
 
 def _check_all(model, ref_grads, rtol=1e-3):
