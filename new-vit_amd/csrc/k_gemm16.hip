@@ -210,6 +210,9 @@ int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw
     // measured on MI355X (tools/bench_gemm.py): the read-modify-write epilogue of the residual GEMMs is
     // HBM-bound and overlaps better with two small workgroups per CU; the others favour the big tile
     static const bool mid_ok = !(getenv("MST_GEMM_MID") && atoi(getenv("MST_GEMM_MID")) == 0);
+    static const bool wreg_ok = !(getenv("MST_GEMM_WREG") && atoi(getenv("MST_GEMM_WREG")) == 0);
+    if (wreg_ok && gemm16_wreg_applicable(M, N, K, dt, cdt, epi, scale_cols, lda, ldc))
+        return launch_gemm16_wreg(A, dt, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
     if (mid_ok && gemm16_mid_applicable(M, N, K, dt, cdt, epi))
         return launch_gemm16_mid(A, dt, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);
     if (big_ok && epi != MST_EPI_RESIDUAL && gemm16_big_applicable(M, N, K))

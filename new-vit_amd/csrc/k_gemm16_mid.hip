@@ -17,7 +17,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 384, BK = 32;
+#ifndef MID_BK
+#define MID_BK 32         // 64: whole 128-byte lines per row and stage (8-row LDS-DMA pieces, 128-byte LDS rows, slot = chunk ^ ((row>>1)&7))
+#endif
+constexpr int BM = 128, BN = 384, BK = MID_BK;
 constexpr int A_BYTES = BM * BK * 2;              // 8 KiB
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
 #ifndef MID_NSTAGE
@@ -27,7 +30,9 @@ constexpr int NSTAGE = MID_NSTAGE;
 constexpr int STG_OFF = NSTAGE * STAGE_BYTES;     // epilogue staging behind the ring
 constexpr int LDS_BYTES = STG_OFF + 4 * 16 * (96 * 4 + 16);   // ring + staging (25.6 KiB covers fp32 rows)
 constexpr int NI = 6, NJ = 8;                     // 16-wide sub-tiles per wave: N, M
-constexpr int PA = 2, PW = 6, PS = PA + PW;       // LDS-DMA pieces per wave per stage: A, W, total
+constexpr int PA = BK / 16, PW = 3 * BK / 16, PS = PA + PW;   // LDS-DMA pieces (1 KiB) per wave per stage: A, W, total
+constexpr int RPP = 1024 / (BK * 2);              // rows per piece (16 / 8)
+constexpr int ROWB_K = BK * 2;                    // LDS row bytes (64 / 128)
 #ifndef MID_NBLK
 #define MID_NBLK 0        // 0 = one workgroup per compute unit of the device
 #endif
@@ -49,24 +54,33 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
     // one L2
     const int bslot = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);   // nblk is a multiple of 8
 
-    const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);   // chunk whose home is slot lane&3
     const int frow = lane & 15;
-    const int fslot = ((lane >> 4) ^ ((0 - (frow >> 2)) & 3)) * 16;
-    const int a_frag_off = frow * 64 + fslot;
-    const int w_frag_off = A_BYTES + (wave * 96 + frow) * 64 + fslot;
+    int srow, schunk, schunk_odd, fslot;
+    if constexpr (BK == 32) {
+        srow = lane >> 2;
+        schunk = schunk_odd = (lane & 3) ^ ((0 - (lane >> 4)) & 3);   // chunk whose home is slot lane&3
+        fslot = ((lane >> 4) ^ ((0 - (frow >> 2)) & 3)) * 16;
+    } else {
+        srow = lane >> 3;                                 // pieces of 8 rows: piece u holds LDS rows 8u + srow, (row>>1)&7 = 4(u&1) + (srow>>1)
+        schunk = (lane & 7) ^ (srow >> 1);
+        schunk_odd = schunk ^ 4;
+        fslot = ((lane >> 4) ^ (frow >> 1)) * 16;         // k-half h: chunk (lane>>4) + 4h -> byte offset ^ 64
+    }
+    const int a_frag_off = frow * ROWB_K + fslot;
+    const int w_frag_off = A_BYTES + (wave * 96 + frow) * ROWB_K + fslot;
 
     const T* a_src[PA];
-    const T* w_src;   // piece u of this wave is at w_src + u*16*ldw
+    const T* w_src;   // piece u of this wave is at w_src + u*RPP*ldw (+- the chunk swap of odd pieces)
+    const int odd_fix = (schunk_odd - schunk) * 8;
     auto set_tile = [&](int tile) {
         const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 #pragma unroll
         for (int u = 0; u < PA; ++u) {
-            int r = m0 + (wave * PA + u) * 16 + srow;
+            int r = m0 + (wave * PA + u) * RPP + srow;
             r = r < M ? r : M - 1;
-            a_src[u] = A + (int64_t)r * lda + schunk * 8;
+            a_src[u] = A + (int64_t)r * lda + ((u & 1) ? schunk_odd : schunk) * 8;
         }
-        w_src = W + (int64_t)(n0 + wave * (PW * 16) + srow) * ldw + schunk * 8;
+        w_src = W + (int64_t)(n0 + wave * (PW * RPP) + srow) * ldw + schunk * 8;
     };
     auto stage = [&](int buf, int kt) {   // PS LDS-DMA per wave
         char* base = smem + buf * STAGE_BYTES;
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
             __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[u] + kt * BK), LDS_PTR(base + (wave * PA + u) * 1024), 16, 0, 0);
 #pragma unroll
         for (int u = 0; u < PW; ++u)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(w_src + (int64_t)u * 16 * ldw + kt * BK),
+            __builtin_amdgcn_global_load_lds(GLB_PTR(w_src + (int64_t)u * RPP * ldw + kt * BK + ((u & 1) ? odd_fix : 0)),
                                              LDS_PTR(base + A_BYTES + (wave * PW + u) * 1024), 16, 0, 0);
     };
 
@@ -113,14 +127,23 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (t + NSTAGE - 1 < nk) stage((ring + t + NSTAGE - 1) % NSTAGE, t + NSTAGE - 1);
             const char* sb = smem + ((ring + t) % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+            for (int h = 0; h < BK / 32; ++h) {
             vec8 wf[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const vec8*>(sb + w_frag_off + i * 16 * 64);
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const vec8*>(sb + ((w_frag_off + i * 16 * ROWB_K) ^ (h * 64)));
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const vec8 af = *reinterpret_cast<const vec8*>(sb + a_frag_off + j * 16 * 64);
+                const vec8 af = *reinterpret_cast<const vec8*>(sb + ((a_frag_off + j * 16 * ROWB_K) ^ (h * 64)));
 #pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i][j] = mfma16(wf[i], af, acc[i][j]);
+                for (int i = 0; i < NI; ++i) {
+#ifdef MID_ABL_NO_MFMA
+                    asm volatile("" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(af));
+#else
+                    acc[i][j] = mfma16(wf[i], af, acc[i][j]);
+#endif
+                }
+            }
             }
         }
 
@@ -135,6 +158,38 @@ __global__ __launch_bounds__(256) void gemm16_mid_kernel(const T* __restrict__ A
                 if (u < nk) stage((ring + u) % NSTAGE, u);
         }
 
+#ifdef MID_ABL_NO_STORE
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+        if (next >= ntiles) break;
+        tile = next;
+        continue;
+#endif
+#ifdef MID_ABL_DIRECT                                  // 8-byte lane pieces straight from the accumulators (32 B per token per instruction)
+        if constexpr (sizeof(OutT) == 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int m = m0 + j * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    typedef __attribute__((ext_vector_type(4))) OutT o4;
+                    o4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r];
+                        if (nb + i * 16 + r < scale_cols) v *= col_scale;
+                        pk[r] = (OutT)v;
+                    }
+                    if (m < M) *reinterpret_cast<o4*>(C + (int64_t)m * ldc + nb + i * 16) = pk;
+                }
+            }
+            if (next >= ntiles) break;
+            tile = next;
+            continue;
+        }
+#endif
         // ---- epilogue: each wave transposes one 16-row x 96-column slab at a time through its private staging area and
         // moves it to / from global memory as 16-byte lane accesses along whole row segments (fp32: 384 B = three lines)
         {

@@ -153,6 +153,9 @@ bool gemm16_big_applicable(int64_t M, int N, int K);
 int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
                       void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                       float col_scale, int scale_cols, hipStream_t s);
+bool gemm16_wreg_applicable(int64_t M, int N, int K, int dt, int cdt, int epi, int scale_cols, int64_t lda, int64_t ldc);
+int launch_gemm16_wreg(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                       int64_t M, int N, float col_scale, int scale_cols, hipStream_t s);
 bool gemm16_mid_applicable(int64_t M, int N, int K, int dt, int cdt, int epi);
 int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
                       int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols,

@@ -525,3 +525,28 @@ def test_znormalize_matches_reference_arithmetic(hip, shape, pct):
     assert float((got.cpu() - ref).abs().max()) < 2e-5
     with pytest.raises(RuntimeError, match="Standard deviation is 0"):
         preprocess.znormalize(torch.tensor([0.0, 1.0, 1.0, 1.0, 2.0]).reshape(1, 1, 1, 5).cuda())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,lda,scale_cols", [(65536 + 77, 384, 384), (70001, 392, 0), (65536, 384, 1152)])
+def test_gemm_weights_in_registers_qkv_shape(dt, M, lda, scale_cols):
+    """k_gemm16_wreg.hip (K = 384, N = 3 x 384, M >= 65536: the QKV projection of the bench): ragged last chunk, strided rows,
+    scaled column ranges aligned to the 384-column tiles; against the fp64 product of the same 16-bit operands, within the
+    rounding of the output type."""
+    from mst import hip
+    N, K = 1152, 384
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, lda, generator=g).to(dt).cuda()[:, :K]
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    full = torch.zeros(M + 40, N, dtype=dt, device="cuda")          # 40 guard rows behind the ragged chunk
+    out = full[:M]
+    lib = hip.load()
+    hip._check(lib.mst_gemm(a.data_ptr(), hip._DT[dt], lda, hip.ptr(w), K, hip.ptr(b), hip.ptr(out), hip._DT[dt], N, M, N, K,
+                            hip.EPI_BIAS, None, 0.125, scale_cols, hip.stream_of(out)), "mst_gemm")
+    ref = a.double() @ w.double().t() + b.double()
+    ref[:, :scale_cols] *= 0.125
+    err = (out.double() - ref).abs()
+    tol = (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * ref.abs().clamp_min(1.0) + 1e-3
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert float(full[M:].float().abs().sum()) == 0                  # rows beyond M are never written

@@ -11,8 +11,11 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 350720
 shapes = {"qkv": (1152, 384, 0), "proj": (384, 384, 3), "fc1": (1536, 384, 1), "fc2": (384, 1536, 3)}
 dt = torch.bfloat16
 torch.manual_seed(0)
+only = sys.argv[2:]
 res = {}
 for name, (N, K, epi) in shapes.items():
+    if only and name not in only:
+        continue
     a = torch.randn(M, K, device="cuda").to(dt)
     w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(dt)
     b = torch.randn(N, device="cuda")
