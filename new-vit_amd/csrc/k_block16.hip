@@ -369,7 +369,11 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 const char* xr = xbase + (row_off(tile, mt) * (E * 4) + g * 32);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
+#ifdef BLOCK_NT
+                    ACC(t, mt) = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 128 * (t >> 1) + 16 * (t & 1))));
+#else
                     ACC(t, mt) = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(xr + 128 * (t >> 1) + 16 * (t & 1)));
+#endif
             }
         };
         auto add_bias = [&](const float* b) {            // 8 vectors in flight per round (the accumulators leave ~40 registers)
@@ -400,7 +404,11 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                     char* xw = (char*)(x + (size_t)tile * 128 * E) + (rloc * (E * 4) + g * 32);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
+#ifdef BLOCK_NT
+                        __builtin_nontemporal_store(__builtin_bit_cast(f32x4, ACC(t, mt)), reinterpret_cast<f32x4*>(xw + 128 * (t >> 1) + 16 * (t & 1)));
+#else
                         *reinterpret_cast<f32x4*>(xw + 128 * (t >> 1) + 16 * (t & 1)) = __builtin_bit_cast(f32x4, ACC(t, mt));
+#endif
                 }
                 if (FINAL && !xn_out) continue;
                 float sum = 0.f;
@@ -436,7 +444,11 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                         o[r] = (T)((a0[r] - mean_o) * rstd);
                         o[4 + r] = (T)((a1[r] - mean_o) * rstd);
                     }
+#ifdef BLOCK_NT
+                    if constexpr (FINAL) __builtin_nontemporal_store(o, reinterpret_cast<vec8*>(xo + 64 * ks));
+#else
                     if constexpr (FINAL) *reinterpret_cast<vec8*>(xo + 64 * ks) = o;
+#endif
                     else {
                         *reinterpret_cast<vec8*>((xs_base + (KS * mt + ks) * 1024) + l16) = o;
 #ifdef BLOCK_DEBUG
