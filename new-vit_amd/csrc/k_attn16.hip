@@ -28,6 +28,12 @@ constexpr int KV_TILE_BYTES = 64 * 128;  // V tile: 64 keys x 64 dims x 2 B
 // 4-bank groups (conflict-free), and every fragment address of a tile becomes ONE lane offset plus an immediate (the
 // XOR made each of the 8 reads its own lane function: ~25 address VALU ops per tile in an issue-bound loop).
 constexpr int K_ROW = 144, K_TILE_BYTES = 64 * K_ROW;
+// -DATTN_NO_DMA restores the register-staged K/V tiles (global_load -> ds_write_b128 behind the MFMAs).  Default: LDS-DMA, 4 pieces
+// of 1 KiB per wave and tile (waves 0-1 the K tile, 2-3 the V tile), both tiles as 128-byte rows whose 16-byte slots are permuted on
+// the SOURCE side (K: slot = chunk ^ ((row >> 1) & 7), V: chunk ^ (((row >> 1) & 1) << 2)), so a piece is still 8 whole rows.
+#ifndef ATTN_NO_DMA
+#define ATTN_DMA 1
+#endif
 
 template <typename T>
 __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const char* p_hi) {
@@ -52,9 +58,14 @@ template <typename T>
 __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                      int N, int heads, int log2q) {
     typedef typename V8<T>::type vec8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * KV_TILE_BYTES];
+#ifdef ATTN_DMA
+    constexpr int KT_BYTES = KV_TILE_BYTES;              // unpadded K rows
+#else
+    constexpr int KT_BYTES = K_TILE_BYTES;
+#endif
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT_BYTES + 2 * KV_TILE_BYTES];
     char* const Ks = smem;
-    char* const Vs = smem + 2 * K_TILE_BYTES;
+    char* const Vs = smem + 2 * KT_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,6 +90,24 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
         for (int ds = 0; ds < 4; ++ds) bq[ds] = *reinterpret_cast<const vec8*>(qp + ds * 16);
     }
 
+#ifdef ATTN_DMA
+    static_assert(WGW == 4, "the LDS-DMA staging map is written for 4 waves (16 pieces per tile)");
+    // piece p = 4 wave + u: p < 8 -> K rows 8p .. 8p+7, else V rows 8(p-8) ..; lane l -> row + (l >> 3), LDS slot l & 7
+    const int d_row0 = (wave & 1) * 32 + (lane >> 3);    // + 8u
+    const int d_isv = wave >> 1;
+    const int d_chunk0 = d_isv ? ((lane & 7) ^ (((d_row0 >> 1) & 1) << 2)) : ((lane & 7) ^ ((d_row0 >> 1) & 7));
+    const int d_col0 = (1 + d_isv) * (heads * 64) + h * 64 + d_chunk0 * 8;       // element column of piece u even; odd K pieces: ^ 32
+    auto dma = [&](int t, int buf) {
+        char* dst = (d_isv ? Vs + buf * KV_TILE_BYTES : Ks + buf * KT_BYTES) + (wave & 1) * 4096;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int key = t * 64 + d_row0 + 8 * u;
+            key = key < N ? key : N - 1;
+            const int col = (u & 1) && !d_isv ? (d_col0 ^ 32) : d_col0;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(base + (int64_t)key * ld + col), LDS_PTR(dst + u * 1024), 16, 0, 0);
+        }
+    };
+#endif
     // ---- K/V staging map: 64 key rows x 8 chunks of 16 B per operand; thread -> key row sr, CPT consecutive chunks
     constexpr int CPT = 512 / WGT;                       // chunks per thread and operand: 2 (4 waves) or 1 (8 waves)
     const int sr = tid / (8 / CPT), sc0 = (tid % (8 / CPT)) * CPT;
@@ -110,6 +139,11 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     // ---- per-lane LDS read offsets
     // K (ds_read_b128): row = kb*32 + (lane&31), 16-byte chunk 2*ds + h2 of a 144-byte row
     const int krow = lane & 31;
+#ifdef ATTN_DMA
+    int k_off4[4];                                       // chunk 2 ds + h2 of row krow: + kb*4096 immediate
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) k_off4[ds] = krow * 128 + (((2 * ds + h2) ^ ((krow >> 1) & 7)) << 4);
+#endif
     const int k_lane_off = krow * K_ROW + h2 * 16;       // + kb*32*K_ROW + ds*32: immediates
     // V (ds_read_b64_tr_b16): 16-lane group g: rows key0 + (i>>2), key0 = ks*16 + 4*h2,
     // columns db*32 + 16*(g&1) + 4*(i&3) .. +3  ->  chunk = db*4 + (g&1)*2 + ((i&3)>>1), +8 B if i odd
@@ -145,8 +179,13 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #endif
 
     const int nt = (N + 63) >> 6;
+#ifdef ATTN_DMA
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     gload(0);
     lstore(0);
+#endif
     __syncthreads();
 
     // one KV tile; MASK = the ragged last tile (keys >= N get -inf).  Peeled so the 32 selects per tile that the
@@ -154,9 +193,15 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     auto tile_step = [&](auto mask_tag, int t) {
         constexpr bool MASK = decltype(mask_tag)::value;
         const int buf = t & 1;
+#ifndef ATTN_ABL_NO_GLOAD
+#ifdef ATTN_DMA
+        if (t + 1 < nt) dma(t + 1, buf ^ 1);             // that buffer was last read in tile t-1: every wave is behind its barrier
+#else
         if (t + 1 < nt) gload(t + 1);
+#endif
+#endif
         if (wave_active) {
-            const char* Kb = Ks + buf * K_TILE_BYTES;
+            const char* Kb = Ks + buf * KT_BYTES;
             const char* Vb = Vs + buf * KV_TILE_BYTES;
             f32x16 s[2];
 #ifdef ATTN_CREF
@@ -164,11 +209,17 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 s[kb] = mfma32(kone, qneg, zero16);      // -r[q] in every key row
+#ifndef ATTN_ABL_NO_QK
 #pragma unroll
                 for (int ds = 0; ds < 4; ++ds) {
+#ifdef ATTN_DMA
+                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_off4[ds] + kb * 4096);
+#else
                     const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
+#endif
                     s[kb] = mfma32(a, bq[ds], s[kb]);
                 }
+#endif
             }
             if constexpr (MASK) {
 #pragma unroll
@@ -179,6 +230,11 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                         if (key >= N) s[kb][r] = -INFINITY;
                     }
             }
+#ifdef ATTN_ABL_NO_MAX
+            float mx = 0.f;
+            asm volatile("" : "+v"(mx));
+            if (t < 0) {
+#else
             float mx = s[0][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -186,6 +242,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (t == 0 || !__all(mx <= RT)) {            // rare after the first tiles: move the reference point
+#endif
                 const bool mv = (t == 0) || (mx > RT);
                 const float r_new = mv ? (float)(T)(r_ref + mx) : r_ref;   // 16-bit representable
                 const float delta = r_new - r_ref;
@@ -206,9 +263,16 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#ifdef ATTN_ABL_NO_EXP
+                    float p = s[kb][r];
+                    asm volatile("" : "+v"(p));
+#else
                     const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+#endif
                     s[kb][r] = p;
+#ifndef ATTN_ABL_NO_SUM
                     lsum += p;
+#endif
                 }
             l_run += lsum;
 #else
@@ -266,15 +330,25 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 for (int j = 0; j < 8; ++j) pf[ks][j] = (T)s[ks >> 1][(ks & 1) * 8 + j];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+#ifdef ATTN_ABL_NO_PV
+                asm volatile("" : "+v"(oT[0]), "+v"(oT[1]) : "v"(pf[ks]));
+#else
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const char* p = Vb + ks * 16 * 128 + v_lane_off + (((db * 4 + vchunk) ^ vsw) * 16);
                     const vec8 vf = tr_pair<T>(p, p + 8 * 128);
                     oT[db] = mfma32(vf, pf[ks], oT[db]);
                 }
+#endif
             }
         }
+#ifndef ATTN_ABL_NO_GLOAD
+#ifdef ATTN_DMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+#else
         if (t + 1 < nt) lstore(buf ^ 1);
+#endif
+#endif
         __syncthreads();
     };
     const int nt_full = (N & 63) ? nt - 1 : nt;
