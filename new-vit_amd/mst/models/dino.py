@@ -309,7 +309,8 @@ class DinoV2ClassifierSlice(BasicClassifier):
         """compute_dtype='fp8' only.  Runs ``forward(source, **kwargs)`` with dynamic scales, records max|x| of the inputs
         of the four linear layers of every block ([depth, 4], kept over successive calls until ``reset_fp8_calibration``),
         and switches later forwards to those scales times ``margin``: LayerNorm and the GELU epilogue then write e4m3 directly
-        and nothing is scanned.  Values beyond the calibrated range saturate.  Returns the scale table (a copy)."""
+        and nothing is scanned.  Values beyond the calibrated range saturate.  Under slice sharding the table is max-reduced over
+        the ranks.  Returns the scale table (a copy)."""
         if self.compute_dtype_name not in hip.FP8_NAMES:
             raise RuntimeError("calibrate_fp8 needs compute_dtype='fp8'")
         if self._fp8_calib is None:
@@ -320,6 +321,8 @@ class DinoV2ClassifierSlice(BasicClassifier):
                 self(source, **kwargs)
         finally:
             self._fp8_collect = False
+        if self._sharding is not None and self._sharding.world_size > 1:
+            self._sharding.all_reduce_max(self._fp8_calib)       # every rank saw other slices: one scale table for all of them
         self._fp8_amax = (self._fp8_calib * float(margin)).contiguous()
         return self._fp8_amax.view(self.encoder.depth, 4).clone()
 

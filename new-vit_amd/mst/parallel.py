@@ -32,6 +32,15 @@ class SliceSharding:
         """One collective on tensors of the group's backend (device tensors over RCCL)."""
         dist.all_gather_into_tensor(out, local, group=self.group)    # rank-major concatenation on dim 0
 
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        """Element-wise maximum over the ranks, in place (the fp8 scale table: every rank must quantise alike).  Built on the one
+        collective `_all_gather`, so a transport that overrides it (tools/rehearsal.py) needs nothing else."""
+        flat = t.contiguous().view(1, -1)
+        out = torch.empty((self.world_size, flat.shape[1]), dtype=t.dtype, device=t.device)
+        self._all_gather(out, flat)
+        t.copy_(out.max(dim=0).values.view(t.shape))
+        return t
+
     def all_gather_slices(self, local: torch.Tensor, D: int) -> torch.Tensor:
         """local [B, dpad, X] (this rank's shard, zero-padded to dpad) -> [B, D, X] on every rank."""
         B, dpad, X = local.shape
