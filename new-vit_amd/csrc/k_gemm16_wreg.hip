@@ -24,6 +24,8 @@
 // (0.161 ms), both together 1.75-1.9 GHz -- 11 % more cycles than the arithmetic alone, 35 % more time
 // (profiles/r02v_qkv_wreg.txt).  Spreading the stores over the k-steps (-DWREG_SPREAD_ST) changes nothing.
 // XCD x (= blockIdx & 7) sweeps the x-th eighth of the chunks; inside it CU g works on column tile g % tiles_n.
+#include <cstdlib>
+
 #include "mst_common.h"
 
 namespace {
@@ -291,8 +293,10 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
 // column range aligned to the tiles, enough 32-row chunks that every CU of an XCD sweeps a few dozen
 bool gemm16_wreg_applicable(int64_t M, int N, int K, int dt, int cdt, int epi, int scale_cols, int64_t lda, int64_t ldc) {
     const int G = mst_persistent_grid() >> 3;
+    const char* e = getenv("MST_GEMM_WREG_MIN_M");    // tests lower the threshold to reach the few-chunks-per-CU paths
+    const int64_t min_m = e ? atoll(e) : 65536;
     return K == KD && N % BN == 0 && N / BN <= G && dt == cdt && epi == MST_EPI_BIAS && (scale_cols % BN == 0 || scale_cols >= N) &&
-           M >= 65536 && M < (1ll << 31) - CH && lda * 2 * CH < (1ll << 31) && ldc * 2 * CH < (1ll << 31) && ldc % 4 == 0;
+           M >= min_m && M < (1ll << 31) - CH && lda * 2 * CH < (1ll << 31) && ldc * 2 * CH < (1ll << 31) && ldc % 4 == 0;
 }
 
 int launch_gemm16_wreg(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,

@@ -550,3 +550,27 @@ def test_gemm_weights_in_registers_qkv_shape(dt, M, lda, scale_cols):
     tol = (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * ref.abs().clamp_min(1.0) + 1e-3
     assert bool((err <= tol).all()), float((err / tol).max())
     assert float(full[M:].float().abs().sum()) == 0                  # rows beyond M are never written
+
+
+@pytest.mark.parametrize("N", [384, 768, 1152, 1536])
+@pytest.mark.parametrize("M", [1, 31, 33, 256 * 32, 256 * 32 * 2 + 7, 256 * 32 * 3 - 1, 11 * 8 * 32 * 4 + 5, 10 * 8 * 32 * 5])
+def test_gemm_weights_in_registers_few_chunks_per_cu(monkeypatch, M, N):
+    """The same kernel with the size threshold lowered (MST_GEMM_WREG_MIN_M): CUs with 0, 1, 2, 3, 4, 5 chunks (the counted-vmcnt
+    table of the prologue iterations and the vmcnt(0) tail), 1-4 column tiles, ragged last chunk; must equal the mid-tile /
+    128 x 128 kernels' result up to the rounding of the output type."""
+    from mst import hip
+    monkeypatch.setenv("MST_GEMM_WREG_MIN_M", "1")
+    K = 384
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    full = torch.zeros(M + 33, N, dtype=torch.bfloat16, device="cuda")
+    out = full[:M]
+    hip.gemm(a, w, b, out=out, col_scale=0.5, scale_cols=384)
+    ref = a.double() @ w.double().t() + b.double()
+    ref[:, :384] *= 0.5
+    err = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs().clamp_min(1.0) + 1e-3
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert float(full[M:].float().abs().sum()) == 0
