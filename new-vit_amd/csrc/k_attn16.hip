@@ -99,20 +99,53 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     }
 
 #ifdef ATTN_DMA
-    static_assert(WGW == 4, "the LDS-DMA staging map is written for 4 waves (16 pieces per tile)");
-    // piece p = 4 wave + u: p < 8 -> K rows 8p .. 8p+7, else V rows 8(p-8) ..; lane l -> row + (l >> 3), LDS slot l & 7
-    const int d_row0 = (wave & 1) * 32 + (lane >> 3);    // + 8u
-    const int d_isv = wave >> 1;
+    static_assert(WGW == 4 || WGW == 8, "the LDS-DMA staging map deals 16 pieces per tile to 4 or 8 waves");
+    // piece p = PPW wave + u: p < 8 -> K rows 8p .. 8p+7, else V rows 8(p-8) ..; lane l -> row + (l >> 3), LDS slot l & 7
+    constexpr int PPW = 16 / WGW;
+    const int d_p0 = wave * PPW;                         // first piece of this wave (even: K odd-piece fix-up goes by u & 1)
+    const int d_row0 = (d_p0 & 7) * 8 + (lane >> 3);     // + 8u
+    const int d_isv = d_p0 >> 3;
     const int d_chunk0 = d_isv ? ((lane & 7) ^ (((d_row0 >> 1) & 1) << 2)) : ((lane & 7) ^ ((d_row0 >> 1) & 7));
     const int d_col0 = (1 + d_isv) * (heads * 64) + h * 64 + d_chunk0 * 8;       // element column of piece u even; odd K pieces: ^ 32
-    auto dma = [&](int t, int buf) {
-        char* dst = (d_isv ? Vs + buf * KV_TILE_BYTES : Ks + buf * KT_BYTES) + (wave & 1) * 4096;
+    // steady state: a scalar tile base + one precomputed 32-bit lane offset per piece -- no vector ALU work per piece (per-piece
+    // address arithmetic was ~40 issue cycles x 4 pieces of a ~1300-cycle tile: -8 % with half the pieces in a timing ablation)
+    unsigned d_off[PPW];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int key = t * 64 + d_row0 + 8 * u;
-            key = key < N ? key : N - 1;
-            const int col = (u & 1) && !d_isv ? (d_col0 ^ 32) : d_col0;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(base + (int64_t)key * ld + col), LDS_PTR(dst + u * 1024), 16, 0, 0);
+    for (int u = 0; u < PPW; ++u) d_off[u] = (unsigned)(((d_row0 + 8 * u) * ld + ((u & 1) && !d_isv ? (d_col0 ^ 32) : d_col0)) * 2);
+    auto dma = [&](int t, int buf) {
+        char* dst = (d_isv ? Vs + buf * KV_TILE_BYTES : Ks + buf * KT_BYTES) + (d_p0 & 7) * 1024;
+#ifdef ATTN_DMA_VADDR
+        if (false) {
+#else
+        if (t * 64 + 64 <= N) {
+#endif
+            const char* tb = reinterpret_cast<const char*>(base) + (int64_t)t * 64 * ld * 2;
+#pragma unroll
+            for (int u = 0; u < PPW; ++u) {
+#ifdef ATTN_ABL_HALF_DMA
+                if (u & 1) continue;
+#endif
+                // saddr + 32-bit lane offset, spelled out: hipcc widens the offsets to 64-bit register pairs and adds the
+                // base per piece otherwise (8 more registers -> spills, one more vector instruction per piece)
+                const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + u * 1024);
+                // (m0 is written here exactly as the builtin of the other branch writes it -- immediately before its one use;
+                // nothing else in this kernel reads it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :
+                             : "v"(d_off[u]), "s"(tb), "s"(m0v)
+                             : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        } else {                                          // ragged last tile: rows beyond N re-read row N-1 (masked later)
+#pragma unroll
+            for (int u = 0; u < PPW; ++u) {
+                int key = t * 64 + d_row0 + 8 * u;
+                key = key < N ? key : N - 1;
+                const int col = (u & 1) && !d_isv ? (d_col0 ^ 32) : d_col0;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(base + (int64_t)key * ld + col), LDS_PTR(dst + u * 1024), 16, 0, 0);
+            }
         }
     };
 #endif
@@ -402,12 +435,16 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
         }
 #ifndef ATTN_ABL_NO_GLOAD
 #ifdef ATTN_DMA
+#ifndef ATTN_ABL_NO_WAIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed
+#endif
 #else
         if (t + 1 < nt) lstore(buf ^ 1);
 #endif
 #endif
+#ifndef ATTN_ABL_NO_BARRIER
         __syncthreads();
+#endif
     };
     const int nt_full = (N & 63) ? nt - 1 : nt;
     for (int t = 0; t < nt_full; ++t) tile_step(std::false_type{}, t);
