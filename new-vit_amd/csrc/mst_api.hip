@@ -425,7 +425,6 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         const int c = (n_slices - s0 < chunk_slices) ? n_slices - s0 : chunk_slices;
         const int64_t Mc = (int64_t)c * N;
         const char* v = (const char*)vol + (size_t)s0 * H * W * in_sz;
-        RUNK(MST_K_PATCH_EMBED, launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
         // fused-LayerNorm pipeline (16-bit, E = 384): norm1 folded into QKV, norm2 + MLP in one kernel.  The fused MLP is a
         // persistent kernel of 128-token tiles: below ~one tile per CU it leaves CUs idle (c1 shape, 4k tokens: 90 us per
         // launch on 33 CUs against ~45 us for LN + fc1 + fc2 as three well-filled launches), so small calls take the unfused
@@ -438,7 +437,15 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         static const bool no_fold = getenv("MST_NO_PROJ_FOLD") && atoi(getenv("MST_NO_PROJ_FOLD"));
         bool folded = fused && !no_fold;
         for (int l = 0; l < w->depth && folded; ++l) folded = w->layers[l].proj_pack && w->layers[l].proj_bf;
-        if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
+        // tokens: in the fused pipeline one kernel writes the residual stream AND block 0's plain-normalised rows (k_patch_rows.hip;
+        // MST_PATCH_ROWS=0: the tiled patch kernel + a LayerNorm launch, the A/B baseline)
+        static const bool patch_rows = !(getenv("MST_PATCH_ROWS") && atoi(getenv("MST_PATCH_ROWS")) == 0);
+        if (fused && patch_rows) {
+            RUNK(MST_K_PATCH_EMBED, launch_patch_rows16(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, x, xn, s));
+        } else {
+            RUNK(MST_K_PATCH_EMBED, launch_patch_embed(v, in_dtype, c, H, W, w->patch_w, dt, w->patch_b, w->prefix, 1 + R, w->pos_patch, E, x, s));
+            if (fused) RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, nullptr, nullptr, xn, dt, E, Mc, E, 1e-6f, s));
+        }
         if (fp8 && !fp8_static && hipMemsetAsync(amax, 0, (size_t)w->depth * 4 * sizeof(float), s) != hipSuccess) {
             mst_set_error("vit_encode: hipMemsetAsync(amax) failed");
             return MST_ELAUNCH;

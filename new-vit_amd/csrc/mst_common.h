@@ -149,6 +149,8 @@ int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b,
 int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
                   void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+int launch_patch_rows16(const void* vol, int idt, int n, int H, int W, const void* wp, int dt, const float* bias, const float* prefix,
+                        int n_prefix, const float* pos_patch, float* x, void* xn, hipStream_t s);
 bool gemm16_big_applicable(int64_t M, int N, int K);
 int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
                       void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
