@@ -459,3 +459,35 @@ def test_extreme_shapes_against_oracle(shape):
     assert bool((torch.isfinite(maps.cpu()) == finite).all())       # N = 2: the only patch is zeroed -> 0/0 in the reference too
     if bool(finite.all()):
         assert rel_l2(maps.cpu(), ref_maps) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", ["nonsquare_fp32_volume", "hub_registers_bf16_volume"])
+def test_fused_token_kernel_against_oracle(case, mode):
+    """k_patch_rows.hip (patch embedding + prefix rows + block 0's LayerNorm in one pass; taken by the fused 16-bit pipeline from
+    12,288 tokens per call): a non-square grid with an fp32 volume and a ragged last chunk of patches, and the hub layout with four
+    register tokens (n_prefix = 5) on a 16-bit volume -- against the CPU oracle at the bars of the fixture tests."""
+    from oracle import mst_oracle as O
+    tl, te, _ = TOL[mode]
+    if case == "nonsquare_fp32_volume":
+        model = build({}, 17, mode)
+        sd = synth.synth_state_dict("s", 17)
+        src = synth.synth_volume((1, 1, 13, 518, 392), 5)                 # 13 x (37 x 28 + 1) = 13,481 tokens; 13,468 patches = 420.9 chunks
+        ref = O.forward(sd, src, keep="cls")
+        vol = src
+    else:
+        from mst.models import DinoV2ClassifierSlice
+        from mst.models.dino import _ViT
+        sd = synth.synth_state_dict("s", 9, img_size=518, layerscale=True, chunked=False, num_register_tokens=4)
+        model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode, use_registers=True)
+        model.encoder = _ViT(384, 12, 6, img_size=518, num_register_tokens=4, layerscale=1.0, chunked=False)
+        model.load_state_dict(sd, strict=True)
+        model = model.cuda().eval()
+        src = synth.synth_volume((1, 1, 10, 518, 518), 6)
+        vol = src.to(torch.bfloat16 if mode == "bf16" else torch.float16)
+        ref = O.forward(sd, vol.float(), keep="cls")
+    with torch.no_grad():
+        logits = model(vol.cuda())
+        emb, _, _ = model.encode_slices(vol.cuda().reshape(-1, vol.shape[-2], vol.shape[-1]))
+    assert rel_l2(emb.cpu(), ref["emb"]) < te
+    assert float((logits.cpu() - ref["logits"]).abs().max()) < tl
