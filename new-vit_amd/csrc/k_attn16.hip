@@ -303,7 +303,16 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+#ifdef ATTN_BPERMUTE
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#else
+            {   // the other half of the query's keys sits 32 lanes away: one v_permlane32_swap instead of an LDS round trip
+                // (ds_bpermute + a wait for every outstanding LDS operation) in the middle of every tile
+                const unsigned mu = __float_as_uint(mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+#endif
             if (t == 0 || !__all(mx <= RT)) {            // rare after the first tiles: move the reference point
 #endif
                 const bool mv = (t == 0) || (mx > RT);
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #endif
                     s[kb][r] = p;
 #ifndef ATTN_ABL_NO_SUM
-                    lsum += p;
+                    lsum += p;                           // one chain: four partial sums measured 3 % slower (registers)
 #endif
                 }
             l_run += lsum;
