@@ -52,9 +52,8 @@ __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const 
     return u.v;
 }
 
-#ifndef ATTN_NO_CREF
-#define ATTN_CREF 1        // reference point subtracted by the matrix pipe (measured -5 % on the bench shape); -DATTN_NO_CREF restores the fma form
-#endif
+// The softmax reference point is subtracted by the matrix pipe (one extra MFMA per 32 keys instead of 32 vector subtractions:
+// measured -5 % on the bench shape when it went in, -9 % against the fma form re-measured with the LDS-DMA tiles).
 #ifndef ATTN_WG_WAVES
 #define ATTN_WG_WAVES 4      // query rows per workgroup = 32 x waves (K/V tiles shared by the workgroup); 8 waves measured 1.5 % slower at N = 1370 (6 x 256 rows pad 12 %, 11 x 128 pad 3 %)
 #endif
@@ -197,7 +196,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     f32x16 oT[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) oT[0][r] = oT[1][r] = 0.f;
-#ifdef ATTN_CREF
     // Scores in the log2 domain (Q fragments pre-multiplied by log2 e) and RELATIVE to a per-query reference point r that the
     // matrix pipe subtracts: the chain of a score tile starts with one extra MFMA  ones[key][k] . (-r)[k][q]  instead of a
     // zero accumulator, so p = exp2(s) needs no per-element fma / sub in this issue-bound loop.  Softmax is invariant to the
@@ -215,9 +213,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
     if (h2 == 0) kone[0] = (T)1.f;
     float r_ref = 0.f, l_run = 0.f;
     constexpr float RT = 8.0f;
-#else
-    float m_run = -INFINITY, l_run = 0.f;
-#endif
 
     const int nt = (N + 63) >> 6;
 #ifdef ATTN_DMA
@@ -245,7 +240,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             const char* Kb = Ks + buf * KT_BYTES;
             const char* Vb = Vs + buf * KV_TILE_BYTES;
             f32x16 s[2];
-#ifdef ATTN_CREF
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #ifdef ATTN_PIPE
             {
@@ -347,54 +341,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #endif
                 }
             l_run += lsum;
-#else
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-                for (int ds = 0; ds < 4; ++ds) {
-                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
-                    s[kb] = mfma32(a, bq[ds], s[kb]);
-                }
-            }
-            if constexpr (MASK) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                        if (key >= N) s[kb][r] = -INFINITY;
-                    }
-            }
-            float mx = s[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            const float mc = m_new * LOG2E;
-            m_run = m_new;
-            float lsum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mc));
-                    s[kb][r] = p;
-                    lsum += p;
-                }
-            l_run = l_run * alpha + lsum;
-            if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    oT[0][r] *= alpha;
-                    oT[1][r] *= alpha;
-                }
-            }
-#endif
             vec8 pf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
