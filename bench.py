@@ -100,6 +100,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--prune-last-block", action="store_true",
+                    help="NOT the headline configuration: the last block computes only what is read behind it (K/V of every "
+                         "token, attention + MLP of the class tokens).  Same results; FLOPs are then counted as executed")
     return ap.parse_args(argv)
 
 
@@ -177,7 +180,7 @@ def main():
     wseed = fixture["seed"] if fixture else 0
 
     model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=args.dtype,
-                                  chunk_slices=args.chunk)
+                                  chunk_slices=args.chunk, prune_last_block=args.prune_last_block)
     model.load_state_dict(synth.synth_state_dict("s", wseed))
     model = model.to(dev).eval()
     if slice_par:
@@ -258,10 +261,15 @@ def main():
         for kind, (ms, cnt) in prof.collect().items():
             if cnt == 0:
                 continue
-            launch_slices = slices_per_rank * sampled_steps * (DEPTH if kind not in ("patch_embed",) else 1) / cnt
+            layers = 1 if kind == "patch_embed" else DEPTH
+            if args.prune_last_block and kind == "block_fused":
+                layers = DEPTH - 1                       # the last block runs on the class-token rows only
+            launch_slices = slices_per_rank * sampled_steps * layers / cnt
             avg_ms = ms / cnt
             kname = kind
             fl = kernel_flops(kname, int(round(launch_slices)), N)
+            if args.prune_last_block and kind in ("attention", "gemm_proj", "gemm_fc1", "gemm_fc2", "layernorm"):
+                fl = 0.0                                 # these kinds mix (or are only) class-token launches: no per-launch rate
             kernels[kname] = {"total_ms": round(ms, 3), "launches": cnt, "avg_ms": round(avg_ms, 4),
                               "tflops": round(fl / (avg_ms * 1e-3) / 1e12, 1) if fl else None}
             if fl and (best is None or ms > best[1]):
@@ -315,6 +323,8 @@ def main():
 
     if rank == 0:
         f_vol = flops_per_volume(D, side, side)
+        if args.prune_last_block:                        # executed, not algorithmic: the last block keeps its K/V projection only
+            f_vol -= D * (4.0 * N * N * E + 18.0 * N * E * E)      # attention + out-projection + MLP of the patch tokens
         par = "single GPU"
         if n_gpus > 1:
             par = (f"slice-sharded x{n_gpus} ({D // n_gpus} slices of every volume per rank) + all-gather of slice embeddings"
@@ -328,7 +338,9 @@ def main():
                                    f"{Bl} volumes{'/GPU' if args.scaling == 'weak' else ' in total'} of "
                                    f"{D}x{args.size}x{args.size} {args.dtype} zero-padded to {side}x{side} (N={N} tokens/slice)",
                        "global_batch_volumes": B, "slices": D, "in_plane": [side, side], "parallelism": par,
-                       "weights": f"synthetic (mst.synth seed {wseed}), random init of the reference architecture"},
+                       "weights": f"synthetic (mst.synth seed {wseed}), random init of the reference architecture",
+                       **({"prune_last_block": "opt-in: dead patch-token work of the last block skipped (same outputs); FLOPs counted "
+                                               "as executed; not the headline configuration"} if args.prune_last_block else {})},
             "achieved_tflops": round(f_vol * value / 1e12, 1),
             "mfma_util": round(f_vol * value / (PEAK[args.dtype] * n_gpus), 4),
             "parity_check": parity,

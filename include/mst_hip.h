@@ -298,6 +298,11 @@ typedef struct mst_vit_weights {
     float* fp8_amax_out;          /* dynamic mode, nullable: device fp32 [depth][4], out[i] = max(out[i], this call's scales):
                                    * zero it, run representative inputs, and pass it back as fp8_amax (calibration) */
     mst_profiler* profiler;       /* nullable: time this call's launches (see mst_profiler_create) */
+    int prune_last_block;         /* 0 (default): every block computes every token, as the reference does.  1: the LAST block
+                                   * computes only what is read behind it -- K and V of every token (and the CLS probabilities /
+                                   * full maps when asked for), then attention, out-projection and MLP of the CLS rows alone.  The
+                                   * reference discards the last block's patch-token outputs (vision_transformer.py:324-329 returns
+                                   * x_norm_clstoken only), so the results are the same; ignored in fp8 mode. */
 } mst_vit_weights;
 
 /* DinoVisionTransformer.forward on n_slices gray slices (vision_transformer.py:254-270,324-329;

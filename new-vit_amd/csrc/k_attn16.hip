@@ -427,7 +427,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 // ---- CLS-row probabilities: softmax_j(q_0 . k_j) per (sequence, head) -> probs[seq][h][N] fp32.
 template <typename T>
 __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qkv, float* __restrict__ probs,
-                                                        int N, int heads, int hd, int log2q) {
+                                                        int N, int heads, int hd, int log2q, T* __restrict__ attn_out = nullptr) {
     extern __shared__ float sm[];  // [hd] q0 | [N] scores | [8] reduce
     float* q0 = sm;
     float* sc = sm + hd;
@@ -482,8 +482,21 @@ __global__ __launch_bounds__(256) void cls_probs_kernel(const T* __restrict__ qk
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-    float* po = probs + ((int64_t)seq * heads + h) * N;
-    for (int j = tid; j < N; j += 256) po[j] = sc[j] * inv;
+    if (probs) {
+        float* po = probs + ((int64_t)seq * heads + h) * N;
+        for (int j = tid; j < N; j += 256) po[j] = sc[j] * inv;
+    }
+    if (attn_out) {   // the CLS query's attention output (hd = 64): o[d] = sum_j p_j v[j][d]; four key ranges x 64 dims, then one add tree
+        float* part = red + 8;                             // [4][64]
+        const int d = tid & 63, pt = tid >> 6;
+        const int per = (N + 3) >> 2;
+        const int j1 = (pt + 1) * per < N ? (pt + 1) * per : N;
+        float a = 0.f;
+        for (int j = pt * per; j < j1; ++j) a = fmaf(sc[j], to_f32(base[(int64_t)j * ld + 2 * E + h * 64 + d]), a);
+        part[pt * 64 + d] = a;
+        __syncthreads();
+        if (tid < 64) attn_out[(int64_t)seq * E + h * 64 + tid] = (T)(((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) * inv);
+    }
 }
 
 // ---- full probabilities (API parity for the `attention_maps` list / rollout): one wave per query.
@@ -679,12 +692,25 @@ int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int h
         return MST_OK;
     }
     const dim3 grid(heads, n_seq), block(256);
-    const size_t sh = (size_t)(hd + N + 8) * sizeof(float);
+    const size_t sh = (size_t)(hd + N + 8 + 256) * sizeof(float);
     if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, hd, log2q);
     else if (dt == MST_F16) cls_probs_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, hd, log2q);
     else if (dt == MST_F32) cls_probs_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, hd, log2q);
     else { mst_set_error("cls_probs: bad dtype %d", dt); return MST_EINVAL; }
     return mst_check_launch("cls_probs");
+}
+
+// The CLS query's attention output only ([n_seq, heads*64] in the operand type; optionally its probabilities too): what the LAST
+// block needs when nothing but the class token is read behind it (mst_vit_weights.prune_last_block).
+int launch_cls_attn(const void* qkv, int dt, int n_seq, int N, int heads, float* probs, void* out, int log2q, hipStream_t s) {
+    MST_CHECK_ARG(N > 0 && N <= 12000 && n_seq > 0 && n_seq <= 65535 && out, "cls_attn: N=%d n_seq=%d unsupported", N, n_seq);
+    const dim3 grid(heads, n_seq), block(256);
+    const size_t sh = (size_t)(64 + N + 8 + 256) * sizeof(float);
+    if (dt == MST_BF16) cls_probs_kernel<bf16_t><<<grid, block, sh, s>>>((const bf16_t*)qkv, probs, N, heads, 64, log2q, (bf16_t*)out);
+    else if (dt == MST_F16) cls_probs_kernel<f16_t><<<grid, block, sh, s>>>((const f16_t*)qkv, probs, N, heads, 64, log2q, (f16_t*)out);
+    else if (dt == MST_F32) cls_probs_kernel<float><<<grid, block, sh, s>>>((const float*)qkv, probs, N, heads, 64, log2q, (float*)out);
+    else { mst_set_error("cls_attn: bad dtype %d", dt); return MST_EINVAL; }
+    return mst_check_launch("cls_attn");
 }
 
 int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q, hipStream_t s) {

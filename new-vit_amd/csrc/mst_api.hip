@@ -430,6 +430,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         // launch on 33 CUs against ~45 us for LN + fc1 + fc2 as three well-filled launches), so small calls take the unfused
         // path.  The choice depends on the WHOLE call (n_slices x N), never on the chunking.
         static const int64_t fused_min_tokens = getenv("MST_FUSED_MIN_TOKENS") ? atoll(getenv("MST_FUSED_MIN_TOKENS")) : 12288;   // measured crossover (tools/bench_crossover.py): 8k tokens unfused 1.57 vs 1.92 ms, 16k fused 2.34 vs 2.62
+        const bool prune = w->prune_last_block && !fp8 && heads * 64 == E && c <= 65535;
         bool fused = !fp8 && (dt != MST_F32) && E == 384 && (int64_t)n_slices * N >= fused_min_tokens;
         for (int l = 0; l < w->depth && fused; ++l)
             fused = w->layers[l].mlp_pack && w->layers[l].fc1_bf && w->layers[l].fc2_bf && w->layers[l].qkv_wf && w->layers[l].qkv_bf;
@@ -473,10 +474,25 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_w, E, L->qkv_b, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             }
             const int li = l - (w->depth - n_layers_probs);
-            if (cls_probs && li >= 0)
-                RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, log2q, s));
             if (full_probs && li >= 0)
                 RUN(launch_probs_full(big, dt, c, N, heads, 64, full_probs + ((int64_t)li * n_slices + s0) * heads * N * N, log2q, s));
+            if (prune && l == w->depth - 1) {
+                // nothing behind this block reads a patch token (final norm + head take the CLS rows): attention, out-projection
+                // and MLP for the c CLS rows only, on the unfused kernels.  Scratch: xn[0, cE) attention rows, xn[cE, 2cE)
+                // LayerNorm2 rows, big (free once K and V are consumed) the hidden rows.
+                const size_t esz = dt == MST_F32 ? 4 : 2;
+                char* const a_cls = (char*)xn;
+                char* const n_cls = (char*)xn + (size_t)c * E * esz;
+                float* const pr = (cls_probs && li >= 0) ? cls_probs + ((int64_t)li * n_slices + s0) * heads * N : nullptr;
+                RUNK(MST_K_ATTENTION, launch_cls_attn(big, dt, c, N, heads, pr, a_cls, log2q, s));
+                RUNK(MST_K_GEMM_PROJ, mst_gemm(a_cls, dt, E, L->proj_w, E, L->proj_b, x, MST_F32, (int64_t)N * E, c, E, E, MST_EPI_RESIDUAL, L->ls1, 1.f, 0, s));
+                RUNK(MST_K_LAYERNORM, launch_layernorm(x, (int64_t)N * E, L->ln2_w, L->ln2_b, n_cls, dt, E, c, E, 1e-6f, s));
+                RUNK(MST_K_GEMM_FC1, mst_gemm(n_cls, dt, E, L->fc1_w, E, L->fc1_b, big, dt, 4 * E, c, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, s));
+                RUNK(MST_K_GEMM_FC2, mst_gemm(big, dt, 4 * E, L->fc2_w, 4 * E, L->fc2_b, x, MST_F32, (int64_t)N * E, c, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, s));
+                continue;
+            }
+            if (cls_probs && li >= 0)
+                RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, log2q, s));
             if (dt == MST_F32) RUNK(MST_K_ATTENTION, launch_attn32((const float*)big, c, N, heads, (float*)xn, s));
             else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
             if (fp8_static) {

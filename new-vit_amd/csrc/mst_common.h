@@ -190,6 +190,7 @@ int launch_block16(float* x, const void* attn, void* xn_out, int dt, const void*
 // second 16-bit rounding of q); 0 = plain head_dim^-0.5 scaling, the public mst_attention* contract
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s);
 int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
+int launch_cls_attn(const void* qkv, int dt, int n_seq, int N, int heads, float* probs, void* out, int log2q, hipStream_t s);
 int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q,
                      hipStream_t s);
 int launch_probs_full(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q,

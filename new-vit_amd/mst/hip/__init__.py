@@ -43,7 +43,7 @@ class VitWeights(C.Structure):
                 ("compute_dtype", _i), ("grid_h", _i), ("grid_w", _i),
                 ("patch_w", _vp), ("patch_b", _vp), ("prefix", _vp), ("pos_patch", _vp),
                 ("layers", C.POINTER(VitLayer)), ("norm_w", _vp), ("norm_b", _vp), ("fp8_linear", _i),
-                ("fp8_amax", _vp), ("fp8_amax_out", _vp), ("profiler", _vp)]
+                ("fp8_amax", _vp), ("fp8_amax_out", _vp), ("profiler", _vp), ("prune_last_block", _i)]
 
 
 class FusionWeights(C.Structure):

@@ -202,6 +202,9 @@ class DinoV2ClassifierSlice(BasicClassifier):
         compute_dtype = str(kwargs.pop("compute_dtype", os.environ.get("MST_COMPUTE_DTYPE", "bf16"))).lower()
         chunk_slices = int(kwargs.pop("chunk_slices", os.environ.get("MST_CHUNK_SLICES", 0)))
         full_attention_maps = bool(kwargs.pop("full_attention_maps", False))
+        # opt-in (default off: every block computes every token, as the reference does): the last block computes only what is read
+        # behind it -- K/V of every token and the attention + MLP of the class tokens; results are the reference's
+        prune_last_block = bool(int(kwargs.pop("prune_last_block", os.environ.get("MST_PRUNE_LAST_BLOCK", 0))))
         if compute_dtype not in hip.DT_NAMES:
             raise ValueError(f"compute_dtype must be one of {sorted(hip.DT_NAMES)}")
         super().__init__(in_ch, out_ch, spatial_dims=spatial_dims, optimizer_kwargs=optimizer_kwargs, **kwargs)
@@ -210,6 +213,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self._fp8_collect = False
         self.chunk_slices = chunk_slices
         self.full_attention_maps = full_attention_maps
+        self.prune_last_block = prune_last_block
         self.save_attn = save_attn
         self.attention_maps = []
         self.attention_maps_slice = []
@@ -516,6 +520,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         pp = self._pos_patch(prep, H, W)
         vit.pos_patch = hip.ptr(pp)
         vit.profiler = self.profiler.handle if self.profiler is not None else None
+        vit.prune_last_block = 1 if self.prune_last_block else 0
         enc = self.encoder
         E, heads = enc.embed_dim, enc.num_heads
         N = 1 + enc.num_register_tokens + vit.grid_h * vit.grid_w

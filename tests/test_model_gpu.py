@@ -491,3 +491,30 @@ def test_fused_token_kernel_against_oracle(case, mode):
         emb, _, _ = model.encode_slices(vol.cuda().reshape(-1, vol.shape[-2], vol.shape[-1]))
     assert rel_l2(emb.cpu(), ref["emb"]) < te
     assert float((logits.cpu() - ref["logits"]).abs().max()) < tl
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp16", "bf16"])
+def test_prune_last_block_gives_the_same_outputs(mode):
+    """Opt-in ``prune_last_block=True``: the last block computes K/V of every token and the attention + MLP of the class tokens
+    only.  Logits, embeddings and every attention read-out must match the reference fixture at the same bars as the full
+    computation, and the full computation itself closely (different kernels for 64 of 87,680 rows: rounding only)."""
+    tl, te, tm = TOL[mode]
+    g = load_golden("c3_1x64x518")
+    src = synth.synth_volume((1, 1, 64, 518, 518), int(g["seed"]) + 100)
+    full = build({}, int(g["seed"]), mode)
+    pruned = build({}, int(g["seed"]), mode, prune_last_block=True)
+    with torch.no_grad():
+        l_full = full(src, save_attn=True)
+        l_pr = pruned(src, save_attn=True)
+        emb, _, _ = pruned.encode_slices(src.cuda().reshape(64, 518, 518))
+    assert rel_l2(emb.cpu(), g["emb"]) < te
+    assert np.abs(l_pr.cpu().numpy() - g["logits"]).max() < tl
+    assert float((l_pr - l_full).abs().max()) < tl
+    sub = g["plane_subset"].tolist()
+    assert rel_l2(pruned.get_slice_attention().cpu(), g["slice_attention"]) < tm
+    assert rel_l2(pruned.get_plane_attention().cpu()[sub], g["plane_attention"]) < tm
+    assert rel_l2(pruned.get_attention_maps().cpu()[sub], g["attention_maps"]) < tm
+    # small call (unfused path) and registers: against the full computation
+    small = synth.synth_volume((2, 1, 5, 112, 84), 3)
+    with torch.no_grad():
+        assert float((pruned(small) - full(small)).abs().max()) < tl
