@@ -58,6 +58,11 @@ def main():
         m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
         m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
         train_case("ResNetSliceTrans(resnet34) training step (fp32 HIP backward)", m, shape)
+    if "--c3" in sys.argv:                               # BASELINE configs[3] per-GPU shape: one LIDC-shaped 128 x 512 x 512 volume
+        m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
+        m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
+        train_case("ResNetSliceTrans(resnet34) training step, BASELINE configs[3] shape", m, (1, 1, 128, 512, 512), n=3)
+        return
     # ViT-B forward at the bench batch (unfused path: LayerNorm + four GEMMs + attention per block)
     m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="b", compute_dtype="bf16")
     m.load_state_dict(synth.synth_state_dict("b", 0))
