@@ -6,7 +6,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "new-vit_amd"))
 import torch
 from mst import hip
-n, N, heads = 256, 1370, 6
+n, N, heads = 256, (int(sys.argv[1]) if len(sys.argv) > 1 else 1370), 6
 dt = torch.bfloat16
 torch.manual_seed(0)
 qkv = (torch.randn(n * N, 3 * heads * 64, device="cuda") * 0.5).to(dt)
@@ -22,4 +22,4 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print({"attn_ms": round(ms, 4), "tflops": round(4.0 * n * N * N * heads * 64 / ms / 1e9, 1)})
+print({"N": N, "attn_ms": round(ms, 4), "tflops": round(4.0 * n * N * N * heads * 64 / ms / 1e9, 1)})
