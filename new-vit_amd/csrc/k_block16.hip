@@ -141,15 +141,33 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
     if (my_tiles <= 0) return;
 
     // ---- LDS-DMA group that lands for local step t of this workgroup's k-th tile, into ring slot `slot` (= global step % 3).
-    // Consumers issue it two steps ahead.  Piece u of wave pr is image piece 4u + pr (1 KiB each).
-    char* const ring_wave = smem + pr * 1024;
+    // Consumers issue it two steps ahead.
+#ifdef BLOCK_DMA_STRIDED                                 // round-2 first form: piece u of wave pr = image piece 4u + pr (1 KiB each)
+    constexpr int WAVE_PIECES = 1024;
+#else                                                    // wave pr takes the six CONSECUTIVE pieces 6 pr .. 6 pr + 5 (see dma_w)
+    constexpr int WAVE_PIECES = 6144;
+#endif
+    char* const ring_wave = smem + pr * WAVE_PIECES;
     auto dma_w = [&](const char* src, char* dst) {       // a 24 KiB image (src wave-uniform): this wave's 6 pieces
 #ifdef BLOCK_NODMA
         return;                                          // timing-only ablation: weights are whatever the LDS holds
 #endif
+#ifdef BLOCK_DMA_STRIDED
 #pragma unroll
         for (int u = 0; u < 6; ++u)
             __builtin_amdgcn_global_load_lds(GLB_PTR((src + u * 4096) + lane16), LDS_PTR(dst + u * 4096), 16, 0, 0);
+#else
+        // the instruction's immediate offset moves BOTH the global and the LDS address: one lane address, one M0, six immediates
+        // (no 64-bit vector add and no M0 write per piece)
+        const auto g = GLB_PTR((src + 2048) + lane16);
+        const auto l = LDS_PTR(dst + 2048);
+        __builtin_amdgcn_global_load_lds(g, l, 16, -2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, -1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+#endif
     };
     // rows of a tile this lane touches: row (16*mt + frow) of the pair's 32, clamped to the last valid row of the matrix
     auto row_off = [&](int tile, int mt) -> unsigned {
@@ -169,11 +187,11 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 __builtin_amdgcn_global_load_lds(GLB_PTR(abase + (row_off(tile, mt) * (E * 2) + g * 16)), LDS_PTR(d + mt * 1024), 16, 0, 0);
-            dma_w(wproj + (size_t)t * W2_BYTES + pr * 1024, ring_wave + W2_RING + slot * W2_BYTES);
+            dma_w(wproj + (size_t)t * W2_BYTES + pr * WAVE_PIECES, ring_wave + W2_RING + slot * W2_BYTES);
             return;
         }
-        if (t < J_G1 + NCHUNK) dma_w(wpack + (size_t)(t - J_G1) * CHUNK_BYTES + pr * 1024, ring_wave + slot * W1_BYTES);
-        if (t >= J_G2) dma_w(wpack + (size_t)(t - J_G2) * CHUNK_BYTES + W1_BYTES + pr * 1024, ring_wave + W2_RING + slot * W2_BYTES);
+        if (t < J_G1 + NCHUNK) dma_w(wpack + (size_t)(t - J_G1) * CHUNK_BYTES + pr * WAVE_PIECES, ring_wave + slot * W1_BYTES);
+        if (t >= J_G2) dma_w(wpack + (size_t)(t - J_G2) * CHUNK_BYTES + W1_BYTES + pr * WAVE_PIECES, ring_wave + W2_RING + slot * W2_BYTES);
     };
     if (!producer) {
         dma_group(0, 0, 0);
