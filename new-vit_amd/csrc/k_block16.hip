@@ -387,7 +387,7 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                 const char* xr = xbase + (row_off(tile, mt) * (E * 4) + g * 32);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-#ifdef BLOCK_NT
+#if defined(BLOCK_NT) || defined(BLOCK_NT_XLD)
                     ACC(t, mt) = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 128 * (t >> 1) + 16 * (t & 1))));
 #else
                     ACC(t, mt) = __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(xr + 128 * (t >> 1) + 16 * (t & 1)));
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                     char* xw = (char*)(x + (size_t)tile * 128 * E) + (rloc * (E * 4) + g * 32);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-#ifdef BLOCK_NT
+#if defined(BLOCK_NT) || defined(BLOCK_NT_XST)
                         __builtin_nontemporal_store(__builtin_bit_cast(f32x4, ACC(t, mt)), reinterpret_cast<f32x4*>(xw + 128 * (t >> 1) + 16 * (t & 1)));
 #else
                         *reinterpret_cast<f32x4*>(xw + 128 * (t >> 1) + 16 * (t & 1)) = __builtin_bit_cast(f32x4, ACC(t, mt));
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512) void block16_kernel(float* x, const T* attn, T
                         o[r] = (T)((a0[r] - mean_o) * rstd);
                         o[4 + r] = (T)((a1[r] - mean_o) * rstd);
                     }
-#ifdef BLOCK_NT
+#if defined(BLOCK_NT) || defined(BLOCK_NT_XN)
                     if constexpr (FINAL) __builtin_nontemporal_store(o, reinterpret_cast<vec8*>(xo + 64 * ks));
 #else
                     if constexpr (FINAL) *reinterpret_cast<vec8*>(xo + 64 * ks) = o;
