@@ -45,7 +45,8 @@ enum mst_epilogue {
 enum mst_fusion_type { MST_FUSION_TRANSFORMER = 0, MST_FUSION_LINEAR = 1, MST_FUSION_AVERAGE = 2 };
 
 /* Library ---------------------------------------------------------------------------------- */
-int mst_version(void);
+int mst_version(void);            /* 100 = round 1; 200 = round 2: mst_vit_layer.proj_pack/proj_bf, mst_fusion_weights.head_in,
+                                   * mst_vit_weights.profiler / prune_last_block appended; the ctypes mirror checks it */
 const char* mst_last_error(void); /* thread-local message of the last failing call */
 
 /* Per-op entry points (unit parity; also what mst_vit_encode / mst_slice_fusion launch) ----- */

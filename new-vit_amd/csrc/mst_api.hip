@@ -92,7 +92,7 @@ static inline size_t dt_size(int dt) { return dt == MST_F32 ? 4 : 2; }
 
 extern "C" {
 
-int mst_version(void) { return 100; }
+int mst_version(void) { return 200; }
 const char* mst_last_error(void) { return g_err; }
 
 int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
 K_COUNT = 10
+ABI_VERSION = 200        # mst_version(): round 2 (struct fields appended since 100)
 
 _lib: Optional[C.CDLL] = None
 
@@ -125,6 +126,9 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.mst_version() != ABI_VERSION:             # the struct mirrors below follow include/mst_hip.h of exactly this version
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.mst_version()}, this binding was written for {ABI_VERSION}: "
+                               "rebuild with `python new-vit_amd/build.py --force`")
         _lib = lib
     return _lib
 

@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in mst_hip.h but not exported"
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
-    assert lib.mst_version() >= 100
+    assert lib.mst_version() == 200
 
 
 def test_missing_library_fails_loudly(tmp_path):
