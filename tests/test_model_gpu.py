@@ -518,3 +518,20 @@ def test_prune_last_block_gives_the_same_outputs(mode):
     small = synth.synth_volume((2, 1, 5, 112, 84), 3)
     with torch.no_grad():
         assert float((pruned(small) - full(small)).abs().max()) < tl
+
+
+@pytest.mark.parametrize("prune", [False, True])
+def test_chunked_equals_unchunked_on_the_fused_16bit_pipeline(prune):
+    """The fused pipeline (token kernel, weights-in-registers QKV, LDS-DMA attention, block kernel) is row-independent and
+    deterministic: encoding 20 slices in chunks of 7 (7 + 7 + 6, the last chunk with other tile / chunk tails) gives bit-identical
+    embeddings and logits; with and without the opt-in last-block pruning."""
+    src = synth.synth_volume((1, 1, 20, 518, 518), 77).to(torch.bfloat16)
+    m1 = build({}, 5, "bf16", prune_last_block=prune)
+    m2 = build({}, 5, "bf16", chunk_slices=7, prune_last_block=prune)
+    with torch.no_grad():
+        l1, l2 = m1(src.cuda(), save_attn=True), m2(src.cuda(), save_attn=True)
+        e1, _, _ = m1.encode_slices(src.cuda().reshape(20, 518, 518))
+        e2, _, _ = m2.encode_slices(src.cuda().reshape(20, 518, 518))
+    assert torch.equal(e1, e2)
+    assert torch.equal(l1, l2)
+    assert torch.equal(m1.get_attention_maps(), m2.get_attention_maps())
