@@ -44,8 +44,17 @@ class _Grads:
         M, N = dY.shape
         K = X.shape[1]
         dev = dY.device
-        dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-        hip.gemm_ex(dY, X, dW, N, K, M, sa=(1, N), sb=(K, 1), sc=(K, 1))
+        # d weight: an [N, K] output reduced over M rows is 36-144 tiles walking thousands of rows each; split the rows into up to
+        # 16 slabs (more workgroups than CUs), partial products reduced by mst_colsum
+        sp = next((d for d in (16, 8, 4, 2) if M % d == 0 and M // d >= 64), 1)
+        if sp > 1:
+            part = torch.empty((sp, N * K), dtype=torch.float32, device=dev)
+            ch = M // sp
+            hip.gemm_ex(dY, X, part, N, K, ch, sa=(1, N), sb=(K, 1), sc=(K, 1), nb=(sp, 1), ba=(ch * N, 0), bb=(ch * K, 0), bc=(N * K, 0))
+            dW = hip.colsum(part, torch.zeros(N * K, dtype=torch.float32, device=dev)).view(N, K)
+        else:
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            hip.gemm_ex(dY, X, dW, N, K, M, sa=(1, N), sb=(K, 1), sc=(K, 1))
         self.put(lin.weight, dW)
         if getattr(lin, "bias", None) is not None:
             self.put(lin.bias, hip.colsum(dY, torch.zeros(N, dtype=torch.float32, device=dev)))
