@@ -50,7 +50,8 @@ def train_case(name, model, shape, n=5):
 
 
 def main():
-    for shape in (((1, 1, 16, 224, 224),) if "--only-dino-c1" in sys.argv else ((1, 1, 16, 224, 224), (2, 1, 32, 224, 224))):
+    dino_shapes = ((1, 1, 16, 224, 224),) if "--only-dino-c1" in sys.argv else ((1, 1, 16, 224, 224), (2, 1, 32, 224, 224))
+    for shape in (() if "--only-resnet" in sys.argv else dino_shapes):
         m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False)
         m.load_state_dict(synth.synth_state_dict("s", 0))
         train_case("DinoV2ClassifierSlice training step (fp32 HIP backward)", m, shape)
@@ -64,6 +65,8 @@ def main():
         m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
         m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
         train_case("ResNetSliceTrans(resnet34) training step, BASELINE configs[3] shape", m, (1, 1, 128, 512, 512), n=3)
+        return
+    if "--only-resnet" in sys.argv:
         return
     # ViT-B forward at the bench batch (unfused path: LayerNorm + four GEMMs + attention per block)
     m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, model_size="b", compute_dtype="bf16")
