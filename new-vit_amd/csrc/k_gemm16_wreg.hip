@@ -290,11 +290,11 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
 }  // namespace
 
 // K = 384 exactly (the register-resident weight slice), 384-column tiles, plain bias epilogue into the operand type, the scaled
-// column range aligned to the tiles, enough 32-row chunks that every CU of an XCD sweeps a few dozen
+// column range aligned to the tiles, at least 8,192 rows (profiles/r02v_qkv_wreg.txt, r03v)
 bool gemm16_wreg_applicable(int64_t M, int N, int K, int dt, int cdt, int epi, int scale_cols, int64_t lda, int64_t ldc) {
     const int G = mst_persistent_grid() >> 3;
     const char* e = getenv("MST_GEMM_WREG_MIN_M");    // tests lower the threshold to reach the few-chunks-per-CU paths
-    const int64_t min_m = e ? atoll(e) : 65536;
+    const int64_t min_m = e ? atoll(e) : 8192;        // measured crossover against the tiled kernels: faster from ~10 k rows (0.047 vs 0.080 ms at 43,840)
     return K == KD && N % BN == 0 && N / BN <= G && dt == cdt && epi == MST_EPI_BIAS && (scale_cols % BN == 0 || scale_cols >= N) &&
            M >= min_m && M < (1ll << 31) - CH && lda * 2 * CH < (1ll << 31) && ldc * 2 * CH < (1ll << 31) && ldc % 4 == 0;
 }
