@@ -46,7 +46,8 @@ enum mst_fusion_type { MST_FUSION_TRANSFORMER = 0, MST_FUSION_LINEAR = 1, MST_FU
 
 /* Library ---------------------------------------------------------------------------------- */
 int mst_version(void);            /* 100 = round 1; 200 = round 2: mst_vit_layer.proj_pack/proj_bf, mst_fusion_weights.head_in,
-                                   * mst_vit_weights.profiler / prune_last_block appended; the ctypes mirror checks it */
+                                   * mst_vit_weights.profiler / prune_last_block appended; 300 = round 3: mst_vit_layer.block_seq
+                                   * inserted, mst_block_fused_s; the ctypes mirror checks it */
 const char* mst_last_error(void); /* thread-local message of the last failing call */
 
 /* Per-op entry points (unit parity; also what mst_vit_encode / mst_slice_fusion launch) ----- */
@@ -209,6 +210,30 @@ int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, con
                     const void* wpack, const float* b1f, const float* b2f, void* scratch, size_t scratch_bytes, int64_t M,
                     int E, float eps, mst_stream_t stream);
 
+/* The same block tail (attention.py:67-68; block.py:90-94,112-113; mlp.py:34-40) as mst_block_fused, in the round-3 SINGLE-ROLE
+ * form: one wave per SIMD owns 32 token rows end to end (y^T accumulators, the LayerNorm2 rows and the hidden activations never
+ * leave its registers), so no scratch and no activation hand-off exist.  Same arithmetic contract and aliasing rules.
+ * block_seq: the block's weights as ONE stream of 108 elements x 24576 B in the order the kernel consumes them --
+ *   12 out-projection chunks, W1(0), then W1(c+1), W2(c) for c = 0..46, then W2(47) -- each element 24 MFMA A-fragments
+ *   [fragment f = 2t+p][lane l][8], m = l & 31, h = l >> 5, k8(e) = 16p + 8(e>>2) + 4h + (e&3):
+ *     out-projection chunk j : ls1[32t+m] * proj_w[32t+m][32j + 16p + 8h + e]
+ *     W1 chunk c (f = k-step): ln2_w[.] * fc1_w[32c+m][32t + k8(e)]
+ *     W2 chunk c             : ls2[32t+m] * fc2_w[32t+m][32c + k8(e)]
+ * b1f fp32 [1536] = fc1_b + fc1_w . ln2_b; proj_bf fp32 [E] = ls1 * proj_b; b2f fp32 [E] = ls2 * fc2_b.
+ * layout: 0 = every operand row-major, or a combination of mst_layout_flags.  The kernel's lanes own ROWS, so a row-major operand
+ * costs 32 scattered 32-byte runs per memory instruction; between two blocks of one encoder the operands stay in the order the
+ * registers hold them (buffers then cover whole groups of 32 rows: round M up to a multiple of 32 when allocating):
+ *   16-bit "blocked" [M/32 groups][24 pieces][64 slots][8]: element (row r, column c) of group g at piece c/16, slot (r%32) + 32*((c/8)%2),
+ *     position c%8 (a piece = one contiguous KiB = 32 rows x 16 consecutive columns; natural column order);
+ *   fp32 "image"     [M/32 groups][48 pieces][64 slots][4]: element (r, c) at piece c/8, slot (r%32) + 32*((c/4)%2), position c%4. */
+enum mst_layout_flags {
+    MST_LAYOUT_X_IN_IMAGE = 1,   /* x is read in the fp32 image layout  */
+    MST_LAYOUT_X_OUT_IMAGE = 2,  /* x is written in the fp32 image layout (in place only when both x flags agree) */
+    MST_LAYOUT_ACT_BLOCKED = 4   /* attn_out is read and xn_out written in the 16-bit blocked layout */
+};
+int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, const void* block_seq, const float* b1f,
+                      const float* proj_bf, const float* b2f, int64_t M, int E, float eps, int layout, mst_stream_t stream);
+
 /* Training step: what torch.autograd does for the reference (base_model.py:148-181, main_train.py:110-126),
  * as per-op entry points; mst/train.py orchestrates them behind a torch.autograd.Function.  All fp32, exact fp32 MFMA.
  * mst_gemm_ex: C[b] = alpha * A[b] . B[b] + beta * C[b], A [M,K], B [K,N], C [M,N] with element strides
@@ -274,6 +299,8 @@ typedef struct mst_vit_layer {
     const void* mlp_pack; const float* fc1_bf; const float* fc2_bf;
     /* with proj_pack / proj_bf (see mst_block_fused) also present for every layer the out-projection joins that launch */
     const void* proj_pack; const float* proj_bf;
+    /* block_seq (see mst_block_fused_s) with fc1_bf / proj_bf / fc2_bf: the single-role launch is taken instead (ABI 300) */
+    const void* block_seq;
     /* Optional FP8 form (mst_vit_weights.fp8_linear): the four block weights as e4m3 bytes, same [out,in] layout, with their
      * per-tensor scales w8_scale[] = max|W|/448 in the order qkv, proj, fc1, fc2 (see mst_gemm_fp8) */
     const void* qkv_w8; const void* proj_w8; const void* fc1_w8; const void* fc2_w8;

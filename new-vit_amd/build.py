@@ -23,7 +23,8 @@ LIB = Path(os.environ.get("MST_BUILD_LIB", HERE / "mst" / "hip" / "libmst_hip.so
 # attention scores in AGPRs and spent 127 v_accvgpr_read/write per KV tile moving them to the softmax and back.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-PER_FILE_FLAGS = {"k_attn16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "k_attn32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+PER_FILE_FLAGS = {"k_block16s.hip": ["-fno-slp-vectorize"],   # the SLP pass re-places the hand-placed GELU / LayerNorm arithmetic (and packs it)
+                  "k_attn16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "k_attn32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def hipcc() -> str:

@@ -92,7 +92,7 @@ static inline size_t dt_size(int dt) { return dt == MST_F32 ? 4 : 2; }
 
 extern "C" {
 
-int mst_version(void) { return 200; }
+int mst_version(void) { return 300; }
 const char* mst_last_error(void) { return g_err; }
 
 int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,
@@ -329,6 +329,13 @@ int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, con
     return launch_block16(x, attn_out, xn_out, dtype, proj_pack, proj_bf, wpack, b1f, b2f, scratch, M, E, eps, (hipStream_t)stream);
 }
 
+int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, const void* block_seq, const float* b1f,
+                      const float* proj_bf, const float* b2f, int64_t M, int E, float eps, int layout, mst_stream_t stream) {
+    MST_CHECK_ARG(x && attn_out && block_seq && b1f && proj_bf && b2f, "block_fused_s: null pointer");
+    MST_CHECK_ARG(layout >= 0 && layout < 8, "block_fused_s: layout=%d", layout);
+    return launch_block16s(x, attn_out, xn_out, dtype, block_seq, b1f, proj_bf, b2f, M, E, eps, layout, (hipStream_t)stream);
+}
+
 // ---- per-slice encoder ----------------------------------------------------------------------
 // workspace carve (chunk of C slices, Mc = C*N rows):
 //   x   fp32 [Mc, E]      residual stream
@@ -438,6 +445,10 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         static const bool no_fold = getenv("MST_NO_PROJ_FOLD") && atoi(getenv("MST_NO_PROJ_FOLD"));
         bool folded = fused && !no_fold;
         for (int l = 0; l < w->depth && folded; ++l) folded = w->layers[l].proj_pack && w->layers[l].proj_bf;
+        // round 3: the single-role block kernel when its weight stream is there (MST_BLOCK_ROLES=1: the producer/consumer form, A/B switch)
+        static const bool roles = getenv("MST_BLOCK_ROLES") && atoi(getenv("MST_BLOCK_ROLES"));
+        bool single_role = folded && !roles;
+        for (int l = 0; l < w->depth && single_role; ++l) single_role = w->layers[l].block_seq != nullptr;
         // tokens: in the fused pipeline one kernel writes the residual stream AND block 0's plain-normalised rows (k_patch_rows.hip;
         // MST_PATCH_ROWS=0: the tiled patch kernel + a LayerNorm launch, the A/B baseline)
         static const bool patch_rows = !(getenv("MST_PATCH_ROWS") && atoi(getenv("MST_PATCH_ROWS")) == 0);
@@ -514,6 +525,11 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUNK(MST_K_GEMM_FC1, launch_gemm8(a8, E, L->fc1_w8, E, L->fc1_b, am + 2, L->w8_scale[2], big, dt, 4 * E, Mc, 4 * E, E, MST_EPI_BIAS_GELU, nullptr, 1.f, 0, am + 3, nullptr, s));
                 RUN(launch_quant8(big, dt, Mc * 4 * E, am + 3, a8, 0, s));
                 RUNK(MST_K_GEMM_FC2, launch_gemm8(a8, 4 * E, L->fc2_w8, 4 * E, L->fc2_b, am + 3, L->w8_scale[3], x, MST_F32, E, Mc, E, 4 * E, MST_EPI_RESIDUAL, L->ls2, 1.f, 0, nullptr, nullptr, s));
+                continue;
+            }
+            if (folded && single_role) {
+                // the same in the single-role form (k_block16s.hip): rows stay in the registers of the wave that owns them
+                RUNK(MST_K_BLOCK_FUSED, launch_block16s(x, xn, (l + 1 < w->depth) ? xn : nullptr, dt, L->block_seq, L->fc1_bf, L->proj_bf, L->fc2_bf, Mc, E, 1e-6f, 0, s));
                 continue;
             }
             if (folded) {

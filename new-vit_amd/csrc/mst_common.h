@@ -186,6 +186,9 @@ int launch_mlp16(float* x, void* xn_out, int dt, const void* wpack, const float*
 size_t block16_scratch_bytes(void);
 int launch_block16(float* x, const void* attn, void* xn_out, int dt, const void* wproj, const float* bproj, const void* wpack,
                    const float* b1f, const float* b2, void* scratch, int64_t M, int E, float eps, hipStream_t s);
+// the same in the single-role form (k_block16s.hip): weights as one stream in consumption order, no scratch
+int launch_block16s(float* x, const void* attn, void* xn_out, int dt, const void* wseq, const float* b1f, const float* bproj,
+                    const float* b2, int64_t M, int E, float eps, int layout, hipStream_t s);
 // log2q: q arrives pre-multiplied by log2(e) as well (the encoder folds it into the QKV epilogue's fp32 q scaling, so no
 // second 16-bit rounding of q); 0 = plain head_dim^-0.5 scaling, the public mst_attention* contract
 int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s);

@@ -34,7 +34,7 @@ _vp, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 class VitLayer(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
-                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf", "proj_pack", "proj_bf",
+                                   "qkv_wf", "qkv_bf", "mlp_pack", "fc1_bf", "fc2_bf", "proj_pack", "proj_bf", "block_seq",
                                    "qkv_w8", "proj_w8", "fc1_w8", "fc2_w8")] + [("w8_scale", C.c_float * 4)]
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mst_mlp_fused": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mst_block_fused_scratch_bytes": (_sz, []),
     "mst_block_fused": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i, _f, _vp]),
+    "mst_block_fused_s": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "mst_gemm_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(_i64), _i, _i, _f, _f, _vp]),
     "mst_softmax_rows": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "mst_softmax_rows_bwd": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
@@ -109,7 +110,7 @@ SIGNATURES = {
     "mst_kernel_kind_name": (C.c_char_p, [_i]),
 }
 K_COUNT = 10
-ABI_VERSION = 200        # mst_version(): round 2 (struct fields appended since 100)
+ABI_VERSION = 300        # mst_version(): round 3 (mst_vit_layer.block_seq, mst_block_fused_s)
 
 _lib: Optional[C.CDLL] = None
 
@@ -319,6 +320,86 @@ def block_fused(x: torch.Tensor, attn_out: torch.Tensor, proj_pack: torch.Tensor
         scratch = torch.empty(int(load().mst_block_fused_scratch_bytes()), dtype=torch.uint8, device=x.device)
     _check(load().mst_block_fused(ptr(x), ptr(attn_out), ptr(xn_out), dt_of(attn_out), ptr(proj_pack), ptr(proj_bf), ptr(wpack),
                                   ptr(b1f), ptr(b2f), ptr(scratch), scratch.numel(), M, E, eps, stream_of(x)), "mst_block_fused")
+
+
+def block_fused_s(x: torch.Tensor, attn_out: torch.Tensor, block_seq: torch.Tensor, b1f: torch.Tensor, proj_bf: torch.Tensor,
+                  b2f: torch.Tensor, xn_out: Optional[torch.Tensor], eps: float = 1e-6, layout: int = 0):
+    """mst_block_fused_s (single-role form of mst_block_fused): x [M,384] fp32 in place += ls1*proj(attn_out) then += the fused
+    MLP; xn_out (may be attn_out itself) receives normalise(x_new).  block_seq / b1f / proj_bf / b2f from pack_block_seq."""
+    _dev(x, "block_fused_s")
+    _dev(attn_out, "block_fused_s")
+    M, E = x.shape
+    _check(load().mst_block_fused_s(ptr(x), ptr(attn_out), ptr(xn_out), dt_of(attn_out), ptr(block_seq), ptr(b1f), ptr(proj_bf),
+                                    ptr(b2f), M, E, eps, layout, stream_of(x)), "mst_block_fused_s")
+
+
+LAYOUT_X_IN_IMAGE, LAYOUT_X_OUT_IMAGE, LAYOUT_ACT_BLOCKED = 1, 2, 4
+
+
+def to_blocked16(a: torch.Tensor) -> torch.Tensor:
+    """Row-major [M, C] (M % 32 == 0, C % 16 == 0) -> the 16-bit "blocked" layout of include/mst_hip.h (test / tooling helper)."""
+    M, Cn = a.shape
+    return a.reshape(M // 32, 32, Cn // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(M, Cn)
+
+
+def from_blocked16(a: torch.Tensor) -> torch.Tensor:
+    M, Cn = a.shape
+    return a.reshape(M // 32, Cn // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).contiguous().reshape(M, Cn)
+
+
+def to_image32(a: torch.Tensor) -> torch.Tensor:
+    """Row-major fp32 [M, C] (M % 32 == 0, C % 8 == 0) -> the fp32 "image" layout of include/mst_hip.h."""
+    M, Cn = a.shape
+    return a.reshape(M // 32, 32, Cn // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(M, Cn)
+
+
+def from_image32(a: torch.Tensor) -> torch.Tensor:
+    M, Cn = a.shape
+    return a.reshape(M // 32, Cn // 8, 2, 32, 4).permute(0, 3, 1, 2, 4).contiguous().reshape(M, Cn)
+
+
+def pack_block_seq(proj_w, proj_b, ls1, fc1_w, fc1_b, fc2_w, fc2_b, ln_w, ln_b, ls2, dtype: torch.dtype):
+    """Host-side packing of one block's out-projection + MLP weights for mst_block_fused_s (layout: include/mst_hip.h): one
+    stream of 108 x 24 KiB elements in the order the kernel consumes them, every element 24 MFMA A-fragments in lane order.
+    LayerNorm2's affine is folded into fc1, LayerScale into proj / fc2 (layer_scale.py:26-27).  Inputs fp32 (any device):
+    proj_w [384,384], proj_b [384], fc1_w [1536,384], fc1_b [1536], fc2_w [384,1536], fc2_b [384], ln_w / ln_b [384], ls1 /
+    ls2 [384] or None.  Returns (block_seq [108, 12288] dtype, b1f [1536] fp32, proj_bf [384] fp32, b2f [384] fp32)."""
+    dev = proj_w.device
+    wp = proj_w.float()
+    pbf = proj_b.float().clone()
+    if ls1 is not None:
+        wp = wp * ls1.float()[:, None]
+        pbf = pbf * ls1.float()
+    w1 = fc1_w.float() * ln_w.float()[None, :]
+    b1f = fc1_b.float() + fc1_w.float() @ ln_b.float()
+    w2 = fc2_w.float()
+    b2f = fc2_b.float().clone()
+    if ls2 is not None:
+        w2 = w2 * ls2.float()[:, None]
+        b2f = b2f * ls2.float()
+    ar = lambda n: torch.arange(n, device=dev)
+    lane = ar(64)
+    m, h = (lane & 31)[None, None, :, None], (lane >> 5)[None, None, :, None]          # [t, p, lane, e]
+    t, p, e = ar(12)[:, None, None, None], ar(2)[None, :, None, None], ar(8)[None, None, None, :]
+    k8 = 16 * p + 8 * (e >> 2) + 4 * h + (e & 3)                                       # accumulator-tile k order within 32
+    rows_t = (32 * t + m).expand(12, 2, 64, 8)
+    # out-projection chunk j: Wp[32t+m][32j + 16p + 8h + e]
+    kp = (16 * p + 8 * h + e).expand(12, 2, 64, 8)
+    proj = torch.stack([wp[rows_t, 32 * j + kp] for j in range(12)])                   # [12, t, p, lane, e]
+    # W1 chunk c, fragment = k-step 2t+p: W1[32c+m][32t + k8]
+    cols1 = (32 * t + k8).expand(12, 2, 64, 8)
+    rows1 = m.expand(12, 2, 64, 8)
+    w1c = torch.stack([w1[32 * c + rows1, cols1] for c in range(48)])                  # [48, t, p, lane, e]
+    # W2 chunk c, fragment 2t+p: W2[32t+m][32c + k8]
+    k2 = k8.expand(12, 2, 64, 8)
+    w2c = torch.stack([w2[rows_t, 32 * c + k2] for c in range(48)])
+    proj, w1c, w2c = proj.reshape(12, -1), w1c.reshape(48, -1), w2c.reshape(48, -1)
+    seq = [proj, w1c[0:1]]
+    inter = torch.stack([w1c[1:48], w2c[0:47]], dim=1).reshape(94, -1)                 # W1(c+1), W2(c) for c = 0..46
+    seq += [inter, w2c[47:48]]
+    block_seq = torch.cat(seq, dim=0).to(dtype).contiguous()
+    assert block_seq.shape == (108, 12288)
+    return block_seq, b1f.contiguous(), pbf.contiguous(), b2f.contiguous()
 
 
 def _w2_row_order(dev):

@@ -421,9 +421,15 @@ class DinoV2ClassifierSlice(BasicClassifier):
                                                    b.norm2.weight.detach().to(dev), b.norm2.bias.detach().to(dev), ls, tdt)
                     ppack, pbf = hip.pack_proj(b.attn.proj.weight.detach().to(dev), b.attn.proj.bias.detach().to(dev),
                                                b.ls1.gamma.detach().to(dev) if hasattr(b, "ls1") else None, tdt)
-                    keep.extend([wpack, b1p, b2p, ppack, pbf])
+                    bseq, _, _, _ = hip.pack_block_seq(b.attn.proj.weight.detach().to(dev), b.attn.proj.bias.detach().to(dev),
+                                                       b.ls1.gamma.detach().to(dev) if hasattr(b, "ls1") else None,
+                                                       b.mlp.fc1.weight.detach().to(dev), b.mlp.fc1.bias.detach().to(dev),
+                                                       b.mlp.fc2.weight.detach().to(dev), b.mlp.fc2.bias.detach().to(dev),
+                                                       b.norm2.weight.detach().to(dev), b.norm2.bias.detach().to(dev), ls, tdt)
+                    keep.extend([wpack, b1p, b2p, ppack, pbf, bseq])
                     L.mlp_pack, L.fc1_bf, L.fc2_bf = hip.ptr(wpack), hip.ptr(b1p), hip.ptr(b2p)
                     L.proj_pack, L.proj_bf = hip.ptr(ppack), hip.ptr(pbf)
+                    L.block_seq = hip.ptr(bseq)
         vit = hip.VitWeights()
         vit.embed_dim, vit.depth, vit.num_heads, vit.num_registers = E, enc.depth, enc.num_heads, R
         vit.compute_dtype = cdt

@@ -253,6 +253,73 @@ def test_block_fused(hip, dt, M, with_ls, with_xn, alias):
         assert float((xc - x2).abs().max() / scale) < 2e-3     # identical weight rounding: only the summation order differs
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,with_ls,with_xn,alias", [(16, False, True, False), (300, True, True, True), (128 * 300 + 5, False, False, False),
+                                                     (41000, True, True, True), (128 * 257, False, True, True)])
+def test_block_fused_single_role(hip, dt, M, with_ls, with_xn, alias):
+    """mst_block_fused_s (round 3: one wave per SIMD owns its rows end to end; weights as one stream in consumption order) vs
+    the same fp64 reference of the reference's block arithmetic as test_block_fused (attention.py:67-68; block.py:89-94,112-113;
+    mlp.py:34-40), and against the producer/consumer kernel on the same operands."""
+    tdt = DT[dt]
+    E, Hd = 384, 1536
+    x = rnd((M, E), 60, 1.5) + 0.3
+    att = (rnd((M, E), 61, 1.0)).to(tdt)
+    wp, bp = rnd((E, E), 62) / math.sqrt(E), rnd((E,), 63) * 0.1
+    w1, b1 = rnd((Hd, E), 51) / math.sqrt(E), rnd((Hd,), 52) * 0.1
+    w2, b2 = rnd((E, Hd), 53) / math.sqrt(Hd), rnd((E,), 54) * 0.1
+    g, be = rnd((E,), 55) * 0.2 + 1, rnd((E,), 56) * 0.2
+    ls1 = (rnd((E,), 64) * 0.3 + 1) if with_ls else None
+    ls2 = (rnd((E,), 57) * 0.3 + 1) if with_ls else None
+    cu = lambda v: None if v is None else v.cuda()
+    seq, b1f, pbf, b2f = hip.pack_block_seq(wp.cuda(), bp.cuda(), cu(ls1), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), g.cuda(),
+                                            be.cuda(), cu(ls2), tdt)
+    xc = x.cuda().clone()
+    attc = att.cuda().clone()
+    xn = (attc if alias else torch.empty(M, E, dtype=tdt, device="cuda")) if with_xn else None
+    hip.block_fused_s(xc, attc, seq, b1f, pbf, b2f, xn)
+    xd = x.double()
+    proj = att.double() @ wp.double().t() + bp.double()
+    xmid = xd + (ls1.double() if ls1 is not None else 1.0) * proj
+    h = torch.nn.functional.layer_norm(xmid, (E,), g.double(), be.double(), 1e-6)
+    h = h @ w1.double().t() + b1.double()
+    h = 0.5 * h * (1 + torch.erf(h / math.sqrt(2)))
+    y = h @ w2.double().t() + b2.double()
+    ref = xmid + (ls2.double() if ls2 is not None else 1.0) * y
+    tol = {"bf16": 1.5e-2, "fp16": 2.5e-3}[dt]
+    scale = max(float(y.abs().max()), float(proj.abs().max()))
+    assert float((xc.double().cpu() - ref).abs().max() / scale) < tol
+    if with_xn:
+        refn = torch.nn.functional.layer_norm(ref, (E,))
+        assert float((xn.double().cpu() - refn).abs().max()) < tol * 4
+    # the producer/consumer kernel on the same operands: same operand rounding, different summation order only
+    wpack, b1p, b2p = hip.pack_mlp(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), g.cuda(), be.cuda(), cu(ls2), tdt)
+    ppack, pbf2 = hip.pack_proj(wp.cuda(), bp.cuda(), cu(ls1), tdt)
+    x2 = x.cuda().clone()
+    att2 = att.cuda().clone()
+    hip.block_fused(x2, att2, ppack, pbf2, wpack, b1p, b2p, None)
+    assert float((xc - x2).abs().max() / scale) < 2e-3
+    # the layouts a block keeps between its neighbours inside one encoder (fp32 image / 16-bit blocked): bit-identical results
+    Mp = (M + 31) // 32 * 32
+    pad = lambda t: torch.cat([t, torch.zeros(Mp - M, E, dtype=t.dtype, device=t.device)])
+    for layout in (hip.LAYOUT_X_IN_IMAGE, hip.LAYOUT_X_OUT_IMAGE, hip.LAYOUT_ACT_BLOCKED, 7):
+        xi = pad(x.cuda())
+        if layout & hip.LAYOUT_X_IN_IMAGE:
+            xi = hip.to_image32(xi)
+        ai = pad(att.cuda())
+        if layout & hip.LAYOUT_ACT_BLOCKED:
+            ai = hip.to_blocked16(ai)
+        same = bool(layout & hip.LAYOUT_X_IN_IMAGE) == bool(layout & hip.LAYOUT_X_OUT_IMAGE)
+        if not same:
+            continue                                     # in place only when both x flags agree (the encoder's first / last block use a second buffer)
+        xo = (ai if alias else torch.empty(Mp, E, dtype=tdt, device="cuda")) if with_xn else None
+        hip.block_fused_s(xi[:M] if not layout & 3 else xi, ai, seq, b1f, pbf, b2f, xo, layout=layout)
+        got_x = (hip.from_image32(xi) if layout & hip.LAYOUT_X_OUT_IMAGE else xi)[:M]
+        assert torch.equal(got_x, xc), layout
+        if with_xn:
+            got_n = (hip.from_blocked16(xo) if layout & hip.LAYOUT_ACT_BLOCKED else xo)[:M]
+            assert torch.equal(got_n, xn[:M]), layout
+
+
 # ---------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, n, N, heads, hd):
     q, k, v = qkv.double().reshape(n, N, 3, heads, hd).permute(2, 0, 3, 1, 4)

@@ -29,13 +29,21 @@ def old():
 def new():
     hip.block_fused(x, att, ppack, pbf, wpack, b1p, b2p, xn, scratch=scratch)
 
-for f in (old, new):
+seq, b1s, pbs, b2s = hip.pack_block_seq(wp, bp, None, w1, b1, w2, b2, g, be, None, dt)
+
+def single():
+    hip.block_fused_s(x, att, seq, b1s, pbs, b2s, xn)
+
+def single_blk():
+    hip.block_fused_s(x, att, seq, b1s, pbs, b2s, xn, layout=7)
+
+for f in (old, new, single, single_blk):
     for _ in range(2):
         f()
 torch.cuda.synchronize()
-res = {"old": [], "new": []}
+res = {"old": [], "new": [], "single": [], "single_blk": []}
 for rnd in range(6):
-    for name, f in (("old", old), ("new", new)):
+    for name, f in (("old", old), ("new", new), ("single", single), ("single_blk", single_blk)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
