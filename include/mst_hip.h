@@ -228,7 +228,8 @@ int mst_block_fused(float* x, const void* attn_out, void* xn_out, int dtype, con
  *   fp32 "image"     [M/32 groups][48 pieces][64 slots][4]: element (r, c) at piece c/8, slot (r%32) + 32*((c/4)%2), position c%4. */
 enum mst_layout_flags {
     MST_LAYOUT_X_IN_IMAGE = 1,   /* x is read in the fp32 image layout  */
-    MST_LAYOUT_X_OUT_IMAGE = 2,  /* x is written in the fp32 image layout (in place only when both x flags agree) */
+    MST_LAYOUT_X_OUT_IMAGE = 2,  /* x is written in the fp32 image layout (in place also when the x flags differ: a 32-row group
+                                  * occupies the same 48 KiB in both layouts and is read whole before it is written) */
     MST_LAYOUT_ACT_BLOCKED = 4   /* attn_out is read and xn_out written in the 16-bit blocked layout */
 };
 int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, const void* block_seq, const float* b1f,

@@ -63,7 +63,7 @@ constexpr int WGW = ATTN_WG_WAVES, WGT = 64 * WGW, QB = 32 * WGW;
 #endif
 template <typename T>
 __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_PER_EU, ATTN_WAVES_PER_EU))) void attn16_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                     int N, int heads, int log2q) {
+                                                     int N, int heads, int log2q, int out_blocked) {
     typedef typename V8<T>::type vec8;
 #ifdef ATTN_DMA
     constexpr int KT_BYTES = KV_TILE_BYTES;              // unpadded K rows
@@ -409,7 +409,13 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / l_tot;
         if (q < N) {
-            T* op = out + ((int64_t)seq * N + q) * E + h * 64 + 4 * h2;
+            // row-major: 8-byte pieces, 16 contiguous bytes per row and instruction.  Blocked (include/mst_hip.h, what the single-role
+            // block kernel reads): feature f = 64 h + 32 db + 8 g + 4 h2 + e of row R sits in piece f / 16, slot (R % 32) + 32 ((f / 8) & 1),
+            // so the 32 query rows of an instruction fill 512 contiguous bytes (two runs where they straddle a 32-row group).
+            const int64_t R = (int64_t)seq * N + q;
+            T* op = out_blocked ? out + (R >> 5) * (32 * E) + (4 * h) * 512 + (R & 31) * 8 + 4 * h2
+                                : out + R * E + h * 64 + 4 * h2;
+            const int sdb = out_blocked ? 1024 : 32, sg2 = out_blocked ? 512 : 16, sg1 = out_blocked ? 256 : 8;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                     o4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pk[e] = (T)(oT[db][g * 4 + e] * inv);
-                    *reinterpret_cast<o4*>(op + db * 32 + 8 * g) = pk;
+                    *reinterpret_cast<o4*>(op + db * sdb + (g >> 1) * sg2 + (g & 1) * sg1) = pk;
                 }
         }
     }
@@ -668,13 +674,13 @@ __global__ __launch_bounds__(256) void probs_full16_kernel(const T* __restrict__
 
 }  // namespace
 
-int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s) {
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s, int out_blocked) {
     MST_CHECK_ARG(n_seq > 0 && N > 0 && heads > 0, "attention: bad sizes n_seq=%d N=%d heads=%d", n_seq, N, heads);
     const int64_t nwg = (int64_t)((N + QB - 1) / QB) * heads * n_seq;
     MST_CHECK_ARG(nwg < (1ll << 31), "attention: grid too large");
     const dim3 grid((unsigned)nwg), block(WGT);
-    if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads, log2q);
-    else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads, log2q);
+    if (dt == MST_BF16) attn16_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)qkv, (bf16_t*)out, N, heads, log2q, out_blocked);
+    else if (dt == MST_F16) attn16_kernel<f16_t><<<grid, block, 0, s>>>((const f16_t*)qkv, (f16_t*)out, N, heads, log2q, out_blocked);
     else { mst_set_error("attention16: bad dtype %d", dt); return MST_EINVAL; }
     return mst_check_launch("attention16");
 }

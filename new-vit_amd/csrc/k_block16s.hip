@@ -40,10 +40,22 @@ constexpr int B2_OFF = BP_OFF + E * 4;                  // fp32 b2     [384]  (l
 constexpr int LDS_BYTES = B2_OFF + E * 4;               // 156,672
 constexpr int NF = 24;                                  // fragments (= MFMAs) per phase
 #ifndef BLOCKS_DEPTH
-#define BLOCKS_DEPTH 5
+#define BLOCKS_DEPTH 4
 #endif
-constexpr int D = BLOCKS_DEPTH;                         // fragment reads in flight ahead of the MFMAs; (D + 1) divides 24
-static_assert(NF % (D + 1) == 0, "fragment ring must tile the phase");
+constexpr int D = BLOCKS_DEPTH;                         // fragment reads in flight ahead of the MFMAs
+// Register sets of the fragment ring: D + 2, not D + 1.  The read issued in slot i must not target the set MFMA i-1 took its A
+// operand from: that MFMA is still executing, and the in-order wave then stalls AT THE READ until it has finished (write-after-read
+// on its source registers) -- measured 44 instead of 32 cycles per slot with D + 1 sets (profiles/r04b_*).
+constexpr int R = D + 2;
+static_assert(NF % R == 0, "fragment ring must tile the phase");
+// Slot i of an out-projection / GEMM2 phase takes fragment FRAG(i) = (tile t = i % 12, k-step p = i / 12): consecutive MFMAs go to
+// DIFFERENT accumulator tiles.  A dependent 32x32x16 MFMA (same accumulator as its predecessor) issued 48 cycles after it, an
+// independent one 32 (stamps: 48.5 cycles per slot in the GEMM1 chain, 44 with dependent pairs; profiles/r04b_*).
+#ifdef BLOCKS_PAIRS
+constexpr int frag_of(int i) { return i; }
+#else
+constexpr int frag_of(int i) { return 2 * (i % 12) + i / 12; }
+#endif
 constexpr int BIAS_SLOT = 8;                            // slot of a phase in which the next chunk's b1 is read
 
 template <int OFF, typename V> __device__ __forceinline__ void lds_read_b128(V& dst, unsigned addr) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
     u32x4 xa[24];                                        // out-projection: attention-output fragments; MLP: normalised rows
     f32x4 hq[2][4];                                      // hidden pre-activations of two chunks in flight, as register quarters
     vec8 hB[2][2];                                       // [chunk parity][k-step]: GELU outputs as GEMM2 B fragments
-    vec8 w[D + 1];                                       // weight fragment ring
+    vec8 w[R];                                           // weight fragment ring
     float ga[8], gb[8], gc[8];                           // GELU scratch of the eight values in flight
 #ifdef BLOCKS_NOFILL
     hB[0][0] = hB[0][1] = hB[1][0] = hB[1][1] = vec8{};
@@ -199,8 +211,11 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
     unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tstart = bstamp();
 #endif
-    auto phase = [&](auto head_tag, auto tail_tag, auto bq_tag, int bias_chunk, auto&& mf, auto&& fill, auto cat_tag) {
+    // ord_tag / nord_tag: 1 = this / the next phase walks its fragments tile-major (frag_of), 0 = in stream order (GEMM1 k-steps)
+    auto phase = [&](auto head_tag, auto tail_tag, auto bq_tag, int bias_chunk, auto&& mf, auto&& fill, auto cat_tag, auto ord_tag, auto nord_tag) {
         constexpr bool HEAD = decltype(head_tag)::value, TAIL = decltype(tail_tag)::value;
+        constexpr int ORD = decltype(ord_tag)::value, NORD = decltype(nord_tag)::value;
+        auto fr = [](int i, int ord) constexpr { return ord ? frag_of(i) : i; };
         constexpr int BQ = decltype(bq_tag)::value, CAT = decltype(cat_tag)::value;
         BST(p0);
         // element ge landed for everybody at the previous barrier; this one publishes ge + 1: own pieces first (all but the 12
@@ -216,11 +231,11 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
         dslot = dslot + 1 == NSLOT ? 0 : dslot + 1;
         const unsigned baddr = b1_lane + 128 * bias_chunk;
         f32x4 bt0, bt1, bt2, bt3;
-        if constexpr (HEAD) static_for<0, D>([&](auto q) { lds_read_b128<decltype(q)::value * 1024>(w[decltype(q)::value % (D + 1)], cur); });
+        if constexpr (HEAD) static_for<0, D>([&](auto q) { lds_read_b128<fr(decltype(q)::value, ORD) * 1024>(w[decltype(q)::value % R], cur); });
         static_for<0, NF>([&](auto it) {
             constexpr int i = decltype(it)::value;
-            if constexpr (i + D < NF) lds_read_b128<(i + D) * 1024>(w[(i + D) % (D + 1)], cur);
-            else if constexpr (TAIL) lds_read_b128<(i + D - NF) * 1024>(w[(i + D) % (D + 1)], nxt);
+            if constexpr (i + D < NF) lds_read_b128<fr(i + D, ORD) * 1024>(w[(i + D) % R], cur);
+            else if constexpr (TAIL) lds_read_b128<fr(i + D - NF, NORD) * 1024>(w[(i + D) % R], nxt);
             if constexpr (BQ >= 0 && i == BIAS_SLOT) {
                 lds_read_b128_acc<0>(bt0, baddr);
                 lds_read_b128_acc<32>(bt1, baddr);
@@ -239,17 +254,13 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
                 hq[BQ < 0 ? 0 : BQ][2] = bt2;
                 hq[BQ < 0 ? 0 : BQ][3] = bt3;
             }
-            mf(it, w[i % (D + 1)]);
+            mf(it, w[i % R]);
 #ifdef BLOCKS_DMA_FRONT
             if constexpr (i == 0) static_for<0, 6>([&](auto u) { dma_piece(my_dsrc, my_dslot, u); });
 #else
             if constexpr (i % 4 == 3) dma_piece(my_dsrc, my_dslot, std::integral_constant<int, i / 4>{});
 #endif
-#ifndef BLOCKS_NOFILL
             fill(it);
-#else
-            if constexpr (i == 0) asm volatile("" : "+v"(hB[0][0]), "+v"(hB[0][1]), "+v"(hB[1][0]), "+v"(hB[1][1]));   // timing-only ablation
-#endif
         });
         slot = nslot;
         BST(p2);
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
     };
     auto gemm2_mf = [&](auto hs_tag) {
         return [&](auto it, const vec8& wf) {
-            constexpr int hs = decltype(hs_tag)::value, i = decltype(it)::value;
+            constexpr int hs = decltype(hs_tag)::value, i = frag_of(decltype(it)::value);
             acc[i >> 1] = mfma32(wf, hB[hs][i & 1], acc[i >> 1]);
         };
     };
@@ -304,67 +315,86 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
     auto gelu_fill = [&](auto hs_tag, auto part_tag) {
         return [&, hs_tag, part_tag](auto it) {
             constexpr int i = decltype(it)::value;
+#ifdef BLOCKS_NOFILL
+            // timing-only ablation: GELU = identity (the packs stay, so GEMM1 stays live)
+            if constexpr (i == 12) static_for<0, 8>([&](auto e) { hB[decltype(hs_tag)::value][decltype(part_tag)::value][decltype(e)::value] = (T)hq[decltype(hs_tag)::value][2 * decltype(part_tag)::value + (decltype(e)::value >> 2)][decltype(e)::value & 3]; });
+            if constexpr (false)
+#else
             if constexpr (i >= 1)
+#endif
                 static_for<0, OPS_PER_SLOT>([&](auto o) { gelu_op(hs_tag, part_tag, std::integral_constant<int, (i - 1) * OPS_PER_SLOT + decltype(o)::value>{}); });
         };
     };
     auto gelu_now = [&](auto hs_tag, auto part_tag) { static_for<0, GOPS>([&](auto n) { gelu_op(hs_tag, part_tag, n); }); };
 
+    // ---- row traffic.  Blocked / image layouts (include/mst_hip.h): every instruction moves one contiguous KiB; row-major: lane =
+    // row, 32 scattered 32-byte runs per instruction (what the first and the last block of an encoder still see).
+    // The rows of tile k + 1 are requested from inside the epilogue of tile k: the attention fragments as soon as xa is dead, the x
+    // pieces tile by tile right behind the stores that free their accumulator registers, so the loads queue behind nothing
+    // (stamps: 14-17 k cycles per tile spent ISSUING 72 loads behind the 72 stores of the epilogue when they came afterwards).
+    const int last_grp = (M - 1) >> 5;
+    auto row_of = [&](int tile) { const int g = tile * 128 + wave * 32 + row32; return (unsigned)(g < M ? g : M - 1); };
+    auto grp_of = [&](int tile) { return (size_t)((tile * 4 + wave) < last_grp ? (tile * 4 + wave) : last_grp); };
+    auto load_attn = [&](int tile) {
+        if (act_blk) {
+            const char* ap = (const char*)attn + (grp_of(tile) * (32 * E * 2) + lane16);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) xa[i] = *reinterpret_cast<const u32x4*>(ap + 1024 * i);
+        } else {
+            const char* ap = (const char*)attn + ((size_t)row_of(tile) * (E * 2) + half * 16);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) xa[i] = *reinterpret_cast<const u32x4*>(ap + 32 * i);
+        }
+    };
+    auto load_x = [&](int tile, auto t_tag) {            // accumulator tile t of the wave's 32 rows
+        constexpr int t = decltype(t_tag)::value;
+        const char* xp = x_in_img ? (const char*)x + (grp_of(tile) * (32 * E * 4) + lane16) + 4096 * t
+                                  : (const char*)x + ((size_t)row_of(tile) * (E * 4) + half * 16) + 128 * t;
+        const int qstep = x_in_img ? 1024 : 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + qstep * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][4 * q + r] = v[r];
+        }
+    };
+    // De-phase the persistent workgroups (k_mlp16.hip): every workgroup runs the same program on the same amount of work, so all 256
+    // tile boundaries (576 KB of row traffic per workgroup) would hit HBM in the same ~10 % of the tile period.  Workgroups with
+    // the smaller tile count start up to a whole tile late for free, the others up to half a tile.
+#ifndef BLOCKS_TILE_CYCLES
+#define BLOCKS_TILE_CYCLES 170000
+#endif
+#ifndef BLOCKS_NO_DEPHASE
+    if (my_tiles >= 4) {
+        const int min_tiles = ntiles / (int)gridDim.x;
+        const unsigned u = (((unsigned)blockIdx.x >> 3) + 5u * ((unsigned)blockIdx.x & 7u)) & 15u;   // 0..15
+        const unsigned long long delay = (unsigned long long)BLOCKS_TILE_CYCLES * ((my_tiles > min_tiles ? 0u : 16u) + u) / 32u;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < 640 && __builtin_readcyclecounter() - t0 < delay; ++it) __builtin_amdgcn_s_sleep(32);   // bounded: every wave leaves
+    }
+#endif
+    load_attn(blockIdx.x);
+    static_for<0, 12>([&](auto t) { load_x(blockIdx.x, t); });
+
     for (int k = 0; k < my_tiles; ++k) {
         const int tile = blockIdx.x + k * gridDim.x;
+        const int next_tile = k + 1 < my_tiles ? tile + (int)gridDim.x : tile;   // (last tile: its own rows once more, unused)
         const int grow = tile * 128 + wave * 32 + row32;                 // this lane's token row
         const bool valid = grow < M;
         const unsigned crow = (unsigned)(valid ? grow : M - 1);
-        // ---- the tile's rows: attention output (16-bit) as 24 B fragments, x (fp32) into the accumulators
         BST(q0);
-        {
-            // (blocked / image layouts: include/mst_hip.h -- every instruction moves one contiguous KiB; row-major: lane = row,
-            // 32 scattered 32-byte runs per instruction, which is what the first and the last block of an encoder still see)
-            const int last_grp = (M - 1) >> 5;
-            const size_t grp = (size_t)((tile * 4 + wave) < last_grp ? (tile * 4 + wave) : last_grp);   // 32-row group of this wave (clamped like the rows)
-            if (act_blk) {
-                const char* ap = (const char*)attn + (grp * (32 * E * 2) + lane16);
-#pragma unroll
-                for (int i = 0; i < 24; ++i) xa[i] = *reinterpret_cast<const u32x4*>(ap + 1024 * i);
-            } else {
-                const char* ap = (const char*)attn + ((size_t)crow * (E * 2) + half * 16);
-#pragma unroll
-                for (int i = 0; i < 24; ++i) xa[i] = *reinterpret_cast<const u32x4*>(ap + 32 * i);
-            }
-            if (x_in_img) {
-                const char* xp = (const char*)x + (grp * (32 * E * 4) + lane16);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 1024 * (4 * t + q));
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][4 * q + r] = v[r];
-                    }
-            } else {
-                const char* xp = (const char*)x + ((size_t)crow * (E * 4) + half * 16);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + 128 * t + 32 * q);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][4 * q + r] = v[r];
-                    }
-            }
-        }
         BST(q1);
         BACC(8, q0, q1);
         // ---- out-projection: 12 phases, acc[t] += Wp chunk j (t, p) . attention columns
         static_for<0, PJ>([&](auto jt) {
             constexpr int j = decltype(jt)::value;
             auto mf = [&](auto it, const vec8& wf) {
-                constexpr int i = decltype(it)::value;
+                constexpr int i = frag_of(decltype(it)::value);
                 acc[i >> 1] = mfma32(wf, __builtin_bit_cast(vec8, xa[2 * j + (i & 1)]), acc[i >> 1]);
             };
-            if constexpr (j == 0) phase(YES, YES, NOBIAS, 0, mf, no_fill, C_PROJ);
-            else if constexpr (j == PJ - 1) phase(NO, NO, I0, 0, mf, no_fill, C_PROJ);           // b1 of chunk 0 -> hq[0]; no prefetch across LayerNorm2
-            else phase(NO, YES, NOBIAS, 0, mf, no_fill, C_PROJ);
+            if constexpr (j == 0) phase(YES, YES, NOBIAS, 0, mf, no_fill, C_PROJ, I1, I1);
+            else if constexpr (j == PJ - 1) phase(NO, NO, I0, 0, mf, no_fill, C_PROJ, I1, I1);           // b1 of chunk 0 -> hq[0]; no prefetch across LayerNorm2
+            else phase(NO, YES, NOBIAS, 0, mf, no_fill, C_PROJ, I1, I1);
         });
         BST(q2);
         // ---- LayerNorm2 on the accumulators (+ b_proj first), normalised rows -> xa, then + b2.  Vector-typed arithmetic on
@@ -422,18 +452,18 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
         BST(q3);
         BACC(9, q2, q3);
         // ---- GEMM1 of chunk 0 (b1 of chunk 1 -> hq[1]), then the first half of its GELU
-        phase(YES, YES, I1, 1, gemm1_mf(I0), no_fill, C_G10);
+        phase(YES, YES, I1, 1, gemm1_mf(I0), no_fill, C_G10, I0, I0);
         wait_lgkm<0>();
         gelu_now(I0, I0);
         // ---- chunks: A(c) = GEMM1(c + 1) beside the second half of GELU(c); B(c) = GEMM2(c) beside the first half of GELU(c + 1)
         // (+ b1 of chunk c + 2 into the buffer GELU(c) has just left)
         auto iter = [&](auto par_tag, auto bias_tag, int c) {
             constexpr int cur = decltype(par_tag)::value, nx = cur ^ 1;
-            phase(NO, YES, NOBIAS, 0, gemm1_mf(std::integral_constant<int, nx>{}), gelu_fill(std::integral_constant<int, cur>{}, I1), C_A);
+            phase(NO, YES, NOBIAS, 0, gemm1_mf(std::integral_constant<int, nx>{}), gelu_fill(std::integral_constant<int, cur>{}, I1), C_A, I0, I1);
             if constexpr (decltype(bias_tag)::value)
-                phase(NO, YES, std::integral_constant<int, cur>{}, c + 2, gemm2_mf(std::integral_constant<int, cur>{}), gelu_fill(std::integral_constant<int, nx>{}, I0), C_B);
-            else
-                phase(NO, YES, NOBIAS, 0, gemm2_mf(std::integral_constant<int, cur>{}), gelu_fill(std::integral_constant<int, nx>{}, I0), C_B);
+                phase(NO, YES, std::integral_constant<int, cur>{}, c + 2, gemm2_mf(std::integral_constant<int, cur>{}), gelu_fill(std::integral_constant<int, nx>{}, I0), C_B, I1, I0);
+            else                                         // chunk 46: the next phase is GEMM2(47)
+                phase(NO, YES, NOBIAS, 0, gemm2_mf(std::integral_constant<int, cur>{}), gelu_fill(std::integral_constant<int, nx>{}, I0), C_B, I1, I1);
         };
 #pragma unroll 1
         for (int c = 0; c < NCHUNK - 2; c += 2) {        // chunks 0 .. 45
@@ -443,39 +473,14 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
         iter(I0, NO, NCHUNK - 2);                        // chunk 46
         wait_lgkm<0>();
         gelu_now(I1, I1);
-        phase(NO, NO, NOBIAS, 0, gemm2_mf(I1), no_fill, C_B); // GEMM2 of chunk 47
-        // ---- the block's output rows: x, then the next block's normalised rows
+        phase(NO, NO, NOBIAS, 0, gemm2_mf(I1), no_fill, C_B, I1, I1); // GEMM2 of chunk 47
+        // ---- the block's output rows: x and the next block's normalised rows, interleaved with the requests for the next tile's rows
         BST(q4);
         {
             const size_t grp = (size_t)tile * 4 + wave;
             const bool grp_valid = (tile * 4 + wave) * 32 < M;           // wave-uniform: groups past M do not exist in the buffers
-            if (x_out_img) {
-              if (grp_valid) {                                             // (rows past M: inside the allocation, never read as rows)
-                char* xp = (char*)x + (grp * (32 * E * 4) + lane16);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[t][4 * q + r];
-                        *reinterpret_cast<f32x4*>(xp + 1024 * (4 * t + q)) = v;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-              }
-            } else if (valid) {
-                char* xp = (char*)x + ((size_t)grow * (E * 4) + half * 16);
-#pragma unroll
-                for (int t = 0; t < 12; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[t][4 * q + r];
-                        *reinterpret_cast<f32x4*>(xp + 128 * t + 32 * q) = v;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            }
+            load_attn(next_tile);                                        // xa is dead since the last GEMM1
+            f32x4 rstd4 = {0.f, 0.f, 0.f, 0.f}, nmr4 = {0.f, 0.f, 0.f, 0.f};
             if (xn_out) {
                 f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
                 static_for<0, 12>([&](auto tt) {
@@ -500,11 +505,27 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
                 sq += __shfl_xor(sq, 32, 64);
                 const float rstd = rsqrtf(sq * (1.0f / E) + eps);
                 const float nmr = -mean * rstd;
-                const f32x4 rstd4 = {rstd, rstd, rstd, rstd}, nmr4 = {nmr, nmr, nmr, nmr};
-                char* const op = act_blk ? (char*)xn_out + (grp * (32 * E * 2) + lane16) : (char*)xn_out + ((size_t)crow * (E * 2) + half * 16);
-                const int ostep = act_blk ? 1024 : 32;
+                rstd4 = f32x4{rstd, rstd, rstd, rstd};
+                nmr4 = f32x4{nmr, nmr, nmr, nmr};
+            }
+            char* const xo = x_out_img ? (char*)x + (grp * (32 * E * 4) + lane16) : (char*)x + ((size_t)grow * (E * 4) + half * 16);
+            const int xt = x_out_img ? 4096 : 128, xq = x_out_img ? 1024 : 32;
+            const bool x_store = x_out_img ? grp_valid : valid;
+            char* const op = act_blk ? (char*)xn_out + (grp * (32 * E * 2) + lane16) : (char*)xn_out + ((size_t)crow * (E * 2) + half * 16);
+            const int ostep = act_blk ? 1024 : 32;
+            const bool n_store = act_blk ? grp_valid : valid;
+            static_for<0, 12>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                if (x_store) {
 #pragma unroll
-                for (int t = 0; t < 12; ++t)
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[t][4 * q + r];
+                        *reinterpret_cast<f32x4*>(xo + xt * t + xq * q) = v;
+                    }
+                }
+                if (xn_out) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         // registers 8p..8p+3 = features 32t + 16p + 4 half + 0..3, registers 8p+4..8p+7 = the same + 8: one
@@ -522,10 +543,18 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
                             o[d2] = sw[0];
                             o[2 + d2] = sw[1];
                         }
-                        if (act_blk ? grp_valid : valid) *reinterpret_cast<u32x4*>(op + ostep * (2 * t + p)) = o;
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (n_store) *reinterpret_cast<u32x4*>(op + ostep * (2 * t + p)) = o;
                     }
-            }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef BLOCKS_EPI_LATE_LOADS
+                load_x(next_tile, tt);                                   // accumulator tile t is free: the next tile's x goes in
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
+#ifdef BLOCKS_EPI_LATE_LOADS
+            static_for<0, 12>([&](auto tt) { load_x(next_tile, tt); });
+#endif
         }
         BST(q5);
         BACC(10, q4, q5);

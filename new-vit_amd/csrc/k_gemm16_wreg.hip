@@ -47,7 +47,10 @@ static_assert(NSLOT == 4, "the counted vmcnt table below is written for three ch
 
 #define WREG_RD(dst, base, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(imm) : "memory")
 
-template <typename T>
+// BLK: A arrives in the 16-bit "blocked" layout of include/mst_hip.h (what the single-role block kernel writes between two blocks of
+// an encoder): a chunk of 32 rows IS 24 contiguous KiB pieces [k/16][row + 32 ((k/8)&1)][8], the LDS slot is a plain copy of it
+// (LDS-DMA with contiguous sources), and a fragment (row 16 mt + frow, k = 32 kt + 8 kq ..+7) sits at one lane offset + immediates.
+template <typename T, bool BLK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm16_wreg_kernel(
     const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw, const float* __restrict__ bias, T* __restrict__ C,
     int64_t ldc, int M, int N, float col_scale, int scale_cols, int nchunks) {
@@ -97,17 +100,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < PPW; ++u) {
         const int o = (wave * PPW + u) * 1024 + lane * 16;
         const int r = o / ROWB;
-        dma_off[u] = (unsigned)(r * (int)lda * 2 + ((((o % ROWB) >> 4) ^ (r & 15)) << 4));
+        dma_off[u] = BLK ? (unsigned)o : (unsigned)(r * (int)lda * 2 + ((((o % ROWB) >> 4) ^ (r & 15)) << 4));
     }
+    const int64_t chunk_bytes = BLK ? (int64_t)SLOT : (int64_t)CH * lda * 2;
     auto issue_piece = [&](int chunk, int slot, int u) {
 #ifdef WREG_ABL_SAME_A
-        const char* base = reinterpret_cast<const char*>(A) + (int64_t)(chunk & 7) * CH * lda * 2;
+        const char* base = reinterpret_cast<const char*>(A) + (int64_t)(chunk & 7) * chunk_bytes;
 #else
-        const char* base = reinterpret_cast<const char*>(A) + (int64_t)chunk * CH * lda * 2;
+        const char* base = reinterpret_cast<const char*>(A) + (int64_t)chunk * chunk_bytes;
 #endif
         unsigned off = dma_off[u];
         const int valid = M - chunk * CH;
-        if (valid < CH) {                           // ragged last chunk: clamp the row
+        if (!BLK && valid < CH) {                   // ragged last chunk: clamp the row (blocked: whole groups are allocated, rows past M are never stored)
             const int o = (wave * PPW + u) * 1024 + lane * 16;
             int r = o / ROWB;
             const int ck = ((o % ROWB) >> 4) ^ (r & 15);
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- fragment reads: row 16 mt + frow, chunk 4 kt + kq  ->  byte r*768 + (kt >> 2)*256 + (((4 (kt & 3) + kq) ^ frow) << 4)
     int rb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = frow * ROWB + (((4 * j + kq) ^ frow) << 4);
+    for (int j = 0; j < 4; ++j) rb[j] = BLK ? (kq >> 1) * 1024 + (frow + 32 * (kq & 1)) * 16 : frow * ROWB + (((4 * j + kq) ^ frow) << 4);
     // ---- epilogue, two parts.  put(): at the end of iteration `it` every wave converts its 32 x 48 results and writes them into
     // staging tile it & 1 (24 consecutive bytes per lane and row).  flush(): behind the NEXT chunk barrier wave w moves rows
     // 4w .. 4w+3 of that tile (768 contiguous bytes each = six whole lines) to C with three 16-byte-per-lane stores.  The tile
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
         u32x4 a[2][2];
         WREG_RD(a[0][0], rbs[0], 0);
-        WREG_RD(a[0][1], rbs[0], 16 * ROWB);
+        if constexpr (BLK) WREG_RD(a[0][1], rbs[0], 256);
+        else WREG_RD(a[0][1], rbs[0], 16 * ROWB);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int cur = kt & 1;
@@ -225,8 +230,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 switch (kt + 1) {                   // immediates must be literals
 #define WREG_NEXT(KN)                                                                  \
     case KN:                                                                           \
-        WREG_RD(a[(KN) & 1][0], rbs[(KN) & 3], ((KN) >> 2) * 256);                     \
-        WREG_RD(a[(KN) & 1][1], rbs[(KN) & 3], 16 * ROWB + ((KN) >> 2) * 256);         \
+        if constexpr (BLK) {                                                           \
+            WREG_RD(a[(KN) & 1][0], rbs[0], (KN) * 2048);                              \
+            WREG_RD(a[(KN) & 1][1], rbs[0], (KN) * 2048 + 256);                        \
+        } else {                                                                       \
+            WREG_RD(a[(KN) & 1][0], rbs[(KN) & 3], ((KN) >> 2) * 256);                 \
+            WREG_RD(a[(KN) & 1][1], rbs[(KN) & 3], 16 * ROWB + ((KN) >> 2) * 256);     \
+        }                                                                              \
         break;
                     WREG_NEXT(1) WREG_NEXT(2) WREG_NEXT(3) WREG_NEXT(4) WREG_NEXT(5) WREG_NEXT(6)
                     WREG_NEXT(7) WREG_NEXT(8) WREG_NEXT(9) WREG_NEXT(10) WREG_NEXT(11)
@@ -275,11 +285,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
-template <typename T>
+template <typename T, bool BLK>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M, int N,
              float cs, int sc, hipStream_t s) {
     static mst_lds_once lds_once;
-    auto kern = gemm16_wreg_kernel<T>;
+    auto kern = gemm16_wreg_kernel<T, BLK>;
     mst_allow_lds((const void*)kern, LDS_BYTES, &lds_once);
     const int nchunks = (int)((M + CH - 1) / CH);
     kern<<<dim3(mst_persistent_grid()), dim3(512), LDS_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (T*)C, ldc, (int)M, N, cs,
@@ -300,9 +310,13 @@ bool gemm16_wreg_applicable(int64_t M, int N, int K, int dt, int cdt, int epi, i
 }
 
 int launch_gemm16_wreg(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
-                       int64_t M, int N, float col_scale, int scale_cols, hipStream_t s) {
-    if (dt == MST_BF16) return launch_t<bf16_t>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
-    if (dt == MST_F16) return launch_t<f16_t>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
+                       int64_t M, int N, float col_scale, int scale_cols, hipStream_t s, int a_blocked) {
+    if (a_blocked) {
+        if (dt == MST_BF16) return launch_t<bf16_t, true>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
+        if (dt == MST_F16) return launch_t<f16_t, true>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
+    }
+    if (dt == MST_BF16) return launch_t<bf16_t, false>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
+    if (dt == MST_F16) return launch_t<f16_t, false>(A, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
     mst_set_error("gemm16_wreg: bad operand dtype %d", dt);
     return MST_EINVAL;
 }

@@ -344,7 +344,8 @@ int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, c
 //   fp8_linear only:  a8 u8 [Mc, 4E] (the quantised input of the current GEMM) | amax f32 [depth][4]
 static void vit_carve(const mst_vit_weights* w, int N, int chunk, size_t* off_xn, size_t* off_big, size_t* total,
                       size_t* off_a8 = nullptr, size_t* off_amax = nullptr, size_t* off_blk = nullptr) {
-    const size_t Mc = (size_t)chunk * N, E = (size_t)w->embed_dim, ts = dt_size(w->compute_dtype);
+    // rows rounded up to whole 32-row groups: the blocked / image layouts between two single-role block launches address groups
+    const size_t Mc = ((size_t)chunk * N + 31) / 32 * 32, E = (size_t)w->embed_dim, ts = dt_size(w->compute_dtype);
     size_t o = 0;
     o += align_up(Mc * E * 4, 256);
     *off_xn = o;
@@ -449,6 +450,13 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
         static const bool roles = getenv("MST_BLOCK_ROLES") && atoi(getenv("MST_BLOCK_ROLES"));
         bool single_role = folded && !roles;
         for (int l = 0; l < w->depth && single_role; ++l) single_role = w->layers[l].block_seq != nullptr;
+        // between two single-role block launches the rows stay in the order the registers hold them (include/mst_hip.h, mst_layout_flags):
+        // x as the fp32 image from block 0's output to the last block's input, the 16-bit rows (attention output, normalised rows)
+        // blocked from block 0's attention on.  Needs the QKV kernel that reads blocked rows (weights-in-registers form) and every
+        // block on the fused path (MST_BLOCK_ROWMAJOR=1: row-major everywhere, A/B switch).
+        static const bool rowmajor = getenv("MST_BLOCK_ROWMAJOR") && atoi(getenv("MST_BLOCK_ROWMAJOR"));
+        const bool blocked = single_role && !rowmajor && !prune && (dt == MST_F16 || dt == MST_BF16) &&
+                             gemm16_wreg_applicable(Mc, 3 * E, E, dt, dt, MST_EPI_BIAS, E, E, 3 * E);
         // tokens: in the fused pipeline one kernel writes the residual stream AND block 0's plain-normalised rows (k_patch_rows.hip;
         // MST_PATCH_ROWS=0: the tiled patch kernel + a LayerNorm launch, the A/B baseline)
         static const bool patch_rows = !(getenv("MST_PATCH_ROWS") && atoi(getenv("MST_PATCH_ROWS")) == 0);
@@ -478,6 +486,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
                 RUNK(MST_K_LAYERNORM, launch_layernorm(x, E, L->ln1_w, L->ln1_b, xn, dt, E, Mc, E, 1e-6f, s));
                 RUN(launch_quant8(xn, dt, Mc * E, am + 0, a8, 1, s));
                 RUNK(MST_K_GEMM_QKV, launch_gemm8(a8, E, L->qkv_w8, E, L->qkv_b, am + 0, L->w8_scale[0], big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, nullptr, nullptr, s));
+            } else if (fused && blocked && l > 0) {
+                RUNK(MST_K_GEMM_QKV, launch_gemm16_wreg(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, 3 * E, Mc, 3 * E, qscale, E, s, 1));
             } else if (fused) {
                 RUNK(MST_K_GEMM_QKV, mst_gemm(xn, dt, E, L->qkv_wf, E, L->qkv_bf, big, dt, 3 * E, Mc, 3 * E, E, MST_EPI_BIAS, nullptr, qscale, E, s));
             } else {
@@ -505,7 +515,7 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             if (cls_probs && li >= 0)
                 RUNK(MST_K_CLS_PROBS, launch_cls_probs(big, dt, c, N, heads, 64, cls_probs + ((int64_t)li * n_slices + s0) * heads * N, log2q, s));
             if (dt == MST_F32) RUNK(MST_K_ATTENTION, launch_attn32((const float*)big, c, N, heads, (float*)xn, s));
-            else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s));
+            else RUNK(MST_K_ATTENTION, launch_attn16(big, dt, c, N, heads, xn, 1, s, blocked ? 1 : 0));
             if (fp8_static) {
                 // the e4m3 hidden activation lives in `big` (bytes); fc1 reads a8 and writes big, fc2 reads big
                 const float* am = w->fp8_amax + l * 4;
@@ -529,7 +539,8 @@ int mst_vit_encode(const mst_vit_weights* w, const void* vol, int in_dtype, int 
             }
             if (folded && single_role) {
                 // the same in the single-role form (k_block16s.hip): rows stay in the registers of the wave that owns them
-                RUNK(MST_K_BLOCK_FUSED, launch_block16s(x, xn, (l + 1 < w->depth) ? xn : nullptr, dt, L->block_seq, L->fc1_bf, L->proj_bf, L->fc2_bf, Mc, E, 1e-6f, 0, s));
+                RUNK(MST_K_BLOCK_FUSED, launch_block16s(x, xn, (l + 1 < w->depth) ? xn : nullptr, dt, L->block_seq, L->fc1_bf, L->proj_bf, L->fc2_bf, Mc, E, 1e-6f,
+                                                       blocked ? (MST_LAYOUT_ACT_BLOCKED | (l > 0 ? MST_LAYOUT_X_IN_IMAGE : 0) | (l + 1 < w->depth ? MST_LAYOUT_X_OUT_IMAGE : 0)) : 0, s));
                 continue;
             }
             if (folded) {

@@ -156,8 +156,9 @@ int launch_gemm16_big(const void* A, int dt, int64_t lda, const void* W, int64_t
                       void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                       float col_scale, int scale_cols, hipStream_t s);
 bool gemm16_wreg_applicable(int64_t M, int N, int K, int dt, int cdt, int epi, int scale_cols, int64_t lda, int64_t ldc);
+// a_blocked: A in the 16-bit blocked layout of include/mst_hip.h (whole 32-row groups allocated; lda ignored)
 int launch_gemm16_wreg(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
-                       int64_t M, int N, float col_scale, int scale_cols, hipStream_t s);
+                       int64_t M, int N, float col_scale, int scale_cols, hipStream_t s, int a_blocked = 0);
 bool gemm16_mid_applicable(int64_t M, int N, int K, int dt, int cdt, int epi);
 int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
                       int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols,
@@ -191,7 +192,8 @@ int launch_block16s(float* x, const void* attn, void* xn_out, int dt, const void
                     const float* b2, int64_t M, int E, float eps, int layout, hipStream_t s);
 // log2q: q arrives pre-multiplied by log2(e) as well (the encoder folds it into the QKV epilogue's fp32 q scaling, so no
 // second 16-bit rounding of q); 0 = plain head_dim^-0.5 scaling, the public mst_attention* contract
-int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s);
+// out_blocked: out in the 16-bit blocked layout of include/mst_hip.h (rows = seq * N + q; whole 32-row groups allocated)
+int launch_attn16(const void* qkv, int dt, int n_seq, int N, int heads, void* out, int log2q, hipStream_t s, int out_blocked = 0);
 int launch_attn32(const float* qkv, int n_seq, int N, int heads, float* out, hipStream_t s);
 int launch_cls_attn(const void* qkv, int dt, int n_seq, int N, int heads, float* probs, void* out, int log2q, hipStream_t s);
 int launch_cls_probs(const void* qkv, int dt, int n_seq, int N, int heads, int hd, float* probs, int log2q,

@@ -7,6 +7,7 @@ sys.path.insert(0, str(ROOT / "new-vit_amd"))
 import numpy as np
 import torch
 from mst import hip
+LAYOUT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 M = 350720; dt = torch.bfloat16; E, H = 384, 1536
 torch.manual_seed(0)
 g = lambda *s: torch.randn(*s, device="cuda")
@@ -16,7 +17,7 @@ seq, b1f, pbf, b2f = hip.pack_block_seq(g(E, E) / E ** .5, g(E) * .1, None, g(H,
 xn = torch.empty(M, E, device="cuda", dtype=dt)
 for _ in range(3):
     x.normal_()
-    hip.block_fused_s(x, att, seq, b1f, pbf, b2f, xn)
+    hip.block_fused_s(x, att, seq, b1f, pbf, b2f, xn, layout=LAYOUT)
 torch.cuda.synchronize()
 lib = hip.load()
 buf = (C.c_ulonglong * (256 * 4 * 16))()
