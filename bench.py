@@ -293,6 +293,19 @@ def main():
                             roofline["traffic_source"] = ent.get("source")
                 except Exception:
                     pass
+            # matrix-pipe busy fraction of the same kernel from a separate rocprofv3 SQ pass (SQ_VALU_MFMA_BUSY_CYCLES / (kernel
+            # cycles x SIMDs)): the counter view of `frac`, quoted only for the exact workload it was taken on
+            sqf = ROOT / "profiles" / "sq_counters.json"
+            if sqf.exists():
+                try:
+                    for ent in json.loads(sqf.read_text()).get("entries", []):
+                        if (ent["dtype"], ent["kernel"], ent["slices_per_launch"], ent["side"]) == \
+                                (args.dtype, kind, slices_per_rank, side):
+                            roofline["mfma_busy_frac"] = ent["mfma_busy_frac"]
+                            roofline["wave_time_split"] = ent.get("wave_time_split")
+                            roofline["counters_source"] = ent.get("source")
+                except Exception:
+                    pass
 
     cpu_baseline = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

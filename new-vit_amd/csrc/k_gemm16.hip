@@ -211,7 +211,10 @@ int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw
     // HBM-bound and overlaps better with two small workgroups per CU; the others favour the big tile
     static const bool mid_ok = !(getenv("MST_GEMM_MID") && atoi(getenv("MST_GEMM_MID")) == 0);
     static const bool wreg_ok = !(getenv("MST_GEMM_WREG") && atoi(getenv("MST_GEMM_WREG")) == 0);
-    if (wreg_ok && gemm16_wreg_applicable(M, N, K, dt, cdt, epi, scale_cols, lda, ldc))
+    // the weights-in-registers kernel moves 16-byte pieces on every operand (LDS-DMA of A, vector loads of W, vector stores of C): a
+    // caller of the C ABI with an odd row pitch or a sliced pointer falls back to the tiled kernels
+    const bool al16 = lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0;
+    if (wreg_ok && al16 && gemm16_wreg_applicable(M, N, K, dt, cdt, epi, scale_cols, lda, ldc))
         return launch_gemm16_wreg(A, dt, lda, W, ldw, bias, C, ldc, M, N, col_scale, scale_cols, s);
     if (mid_ok && gemm16_mid_applicable(M, N, K, dt, cdt, epi))
         return launch_gemm16_mid(A, dt, lda, W, ldw, bias, C, ldc, M, N, K, epi, gamma, col_scale, scale_cols, s);

@@ -197,9 +197,11 @@ __global__ void act_fwd_kernel(const float* __restrict__ h, float* __restrict__ 
 // out[j] += sum_i a[i][j] * (b ? b[i][j] : 1): thread per column, a block per chunk of rows.
 __global__ void colsum_kernel(const float* __restrict__ a, int64_t as, const float* __restrict__ b, int64_t bs, int64_t rows, int cols,
                               int rows_per_block, float* __restrict__ out) {
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    // row blocks on gridDim.x (2^31 - 1 blocks), column blocks on gridDim.y: the stem's BatchNorm sums of a 2 x 128 x 512^2 ResNet
+    // step have 16.8 M rows = 65,536 row blocks, one more than gridDim.y takes
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < cols; c += gridDim.y * blockDim.x) {
         float s = 0.f;
         for (int64_t r = r0; r < r1; ++r) s = fmaf(a[r * as + c], b ? b[r * bs + c] : 1.f, s);
         atomicAdd(out + c, s);
@@ -319,7 +321,8 @@ int launch_act_fwd(const float* h, float* y, int64_t n, int kind, hipStream_t s)
 
 int launch_colsum(const float* a, int64_t as, const float* b, int64_t bs, int64_t rows, int cols, float* out, hipStream_t s) {
     const int rpb = 256;
-    colsum_kernel<<<dim3((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s>>>(a, as, b, bs, rows, cols, rpb, out);
+    MST_CHECK_ARG(rows > 0 && cols > 0 && (rows + rpb - 1) / rpb < (1ll << 31) && (cols + 255) / 256 <= 65535, "colsum: rows=%lld cols=%d out of range", (long long)rows, cols);
+    colsum_kernel<<<dim3((unsigned)((rows + rpb - 1) / rpb), (cols + 255) / 256), dim3(256), 0, s>>>(a, as, b, bs, rows, cols, rpb, out);
     return mst_check_launch("colsum");
 }
 

@@ -205,6 +205,9 @@ class DinoV2ClassifierSlice(BasicClassifier):
         # opt-in (default off: every block computes every token, as the reference does): the last block computes only what is read
         # behind it -- K/V of every token and the attention + MLP of the class tokens; results are the reference's
         prune_last_block = bool(int(kwargs.pop("prune_last_block", os.environ.get("MST_PRUNE_LAST_BLOCK", 0))))
+        # hipGraph replay of the inference forward for small fixed shapes (launch-bound: ~90 launches of 5-10 us each at 16 x 224^2).
+        # "auto": calls of at most MST_GRAPH_MAX_TOKENS tokens; 0 / 1 force it off / on.  Results are the eager ones bit for bit.
+        use_graph = str(kwargs.pop("use_graph", os.environ.get("MST_USE_GRAPH", "auto"))).lower()
         if compute_dtype not in hip.DT_NAMES:
             raise ValueError(f"compute_dtype must be one of {sorted(hip.DT_NAMES)}")
         super().__init__(in_ch, out_ch, spatial_dims=spatial_dims, optimizer_kwargs=optimizer_kwargs, **kwargs)
@@ -214,6 +217,8 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self.chunk_slices = chunk_slices
         self.full_attention_maps = full_attention_maps
         self.prune_last_block = prune_last_block
+        self.use_graph = use_graph
+        self._graphs = {}
         self.save_attn = save_attn
         self.attention_maps = []
         self.attention_maps_slice = []
@@ -275,6 +280,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
     def _invalidate_prepared(self):
         self._param_epoch = getattr(self, "_param_epoch", 0) + 1
         self._prep = self._prep_sig = self._sentinels = None
+        self._graphs = {}                               # captured graphs hold pointers into the prepared weight images
 
     # ---- checkpoint compatibility ---------------------------------------------------------------
     def _remap_state_dict(self, state_dict, prefix, *args):
@@ -336,16 +342,27 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self._fp8_collect = False
 
     def _signature(self, full: bool):
-        """Identity of everything ``_prepare`` folded into device-side weight images.  Walking all ~200 parameters costs
-        ~50 us per forward (5 % of the 1.1 ms c1 forward), so with grad disabled the walk is replaced by an epoch counter
-        that every path which can replace or rewrite parameters bumps (``_apply`` = .to/.cuda/.half, ``load_state_dict``)
-        plus the versions of four sentinel tensors; with grad enabled (optimiser steps rewrite in place) all are walked."""
+        """Identity of everything ``_prepare`` folded into device-side weight images.  With grad enabled (optimiser steps rewrite
+        parameters in place) every parameter's (data_ptr, _version) pair is part of the signature.  With grad disabled the walk
+        is ONE pass over a cached parameter list summing ``_version`` and folding ``data_ptr`` (~15 us for ~200 tensors: a tuple of
+        200 pairs cost ~50 us, 5 % of the 1.1 ms c1 forward): any in-place edit of ANY parameter -- weight surgery on one block,
+        ``model.slice_fusion.load_state_dict(...)``, a partial fine-tune -- changes it (four sentinel tensors did not)."""
         head = (self.compute_dtype_name, None if self._fp8_amax is None else (self._fp8_amax.data_ptr(), self._fp8_amax._version),
                 self._fp8_collect, self._param_epoch)
-        ps = list(self.parameters()) if (full or self._sentinels is None) else self._sentinels
         if self._sentinels is None:
-            self._sentinels = [ps[0], ps[len(ps) // 3], ps[2 * len(ps) // 3], ps[-1]]
-        return head + tuple((q.data_ptr(), q._version) for q in (ps if full else self._sentinels))
+            self._sentinels = list(self.parameters())       # rebuilt by _invalidate_prepared (``_apply`` / load_state_dict replace tensors)
+        ps = self._sentinels
+        if full:
+            return head + tuple((q.data_ptr(), q._version) for q in ps)
+        acc = 0
+        for q in ps:
+            acc = (acc * 1000003 + q._version + q.data_ptr()) & 0xFFFFFFFFFFFFFFFF
+        return head + (acc, len(ps))
+
+    def invalidate(self):
+        """Public: drop every prepared device-side weight image (call after editing parameters through ``.data`` views that bypass
+        the version counters)."""
+        self._invalidate_prepared()
 
     def _apply(self, fn, *args, **kwargs):
         self._invalidate_prepared()
@@ -578,6 +595,69 @@ class DinoV2ClassifierSlice(BasicClassifier):
         B, C, D0, H, W = x.shape
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             x = x.float()
+        if self._graph_wanted(x, save_attn, kwargs):
+            return self._forward_graph(x, save_attn, src_key_padding_mask, kwargs)
+        return self._forward_eager(x, save_attn, src_key_padding_mask, kwargs)
+
+    # ---- hipGraph replay (small fixed shapes) -----------------------------------------------------------------------------
+    def _graph_wanted(self, x, save_attn, kwargs) -> bool:
+        if self.use_graph in ("0", "false", "off") or x.device.type != "cuda":
+            return False
+        if (self._sharding is not None and self._sharding.world_size > 1) or self.profiler is not None or self._fp8_collect:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        if self.use_graph in ("1", "true", "on"):
+            return True
+        B, C, D0, H, W = x.shape
+        tokens = B * C * D0 * (1 + self.encoder.num_register_tokens + (H // PATCH) * (W // PATCH))
+        return tokens <= int(os.environ.get("MST_GRAPH_MAX_TOKENS", 40000)) and not (save_attn and self.full_attention_maps)
+
+    def _forward_graph(self, x, save_attn, mask, kwargs):
+        """Replay of a captured eager forward.  Key: everything that selects kernels or buffer sizes.  The first TWO calls of a key
+        run eagerly (lazy one-time work -- LDS attributes, workspaces, position-grid interpolation -- must not happen inside a
+        capture); the third captures.  Inputs are copied into the graph's static buffers, outputs are cloned out of them."""
+        prep = self._prepare()
+        without_linear = bool(kwargs.get("without_linear", False))
+        key = (tuple(x.shape), x.dtype, bool(save_attn), mask is not None, without_linear, id(prep), torch.cuda.current_device())
+        ent = self._graphs.get(key)
+        if ent is None or ent["graph"] is None:
+            out = self._forward_eager(x, save_attn, mask, kwargs)
+            if ent is None:
+                self._graphs[key] = {"graph": None, "calls": 1}
+                return out
+            ent["calls"] += 1
+            if ent["calls"] < 3:
+                return out
+            # capture on a side stream, as torch.cuda.graph does; static copies of the inputs
+            sx = x.clone()
+            sm = None if mask is None else mask.to(self.device).clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    sout = self._forward_eager(sx, save_attn, sm, kwargs)
+                    state = (self.attention_maps, self.attention_maps_slice, getattr(self, "_cls_last", None)) if save_attn else None
+            except Exception:
+                self._graphs[key] = {"graph": None, "calls": -(1 << 30)}     # this key stays eager
+                return out
+            ent.update(graph=g, x=sx, mask=sm, out=sout, state=state)
+            return out
+        ent["x"].copy_(x)
+        if ent["mask"] is not None:
+            ent["mask"].copy_(mask)
+        ent["graph"].replay()
+        if save_attn:
+            maps, maps_slice, cls_last = ent["state"]
+            self.attention_maps = [m.clone() for m in maps]
+            self.attention_maps_slice = [m.clone() for m in maps_slice]
+            self._cls_last = None if cls_last is None else cls_last.clone()
+        self._local = None
+        self._last_shape = (x.shape[0], x.shape[1] * x.shape[2])
+        return ent["out"].clone()
+
+    def _forward_eager(self, x, save_attn, src_key_padding_mask, kwargs):
+        B, C, D0, H, W = x.shape
         if C != 1:
             x = x.permute(0, 2, 1, 3, 4)                # 'b c d h w -> (b d c) h w'  (dino.py:125)
         D = D0 * C

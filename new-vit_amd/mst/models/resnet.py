@@ -152,8 +152,17 @@ class ResNet(BasicClassifier):
         return super()._apply(fn, *args, **kwargs)
 
     # ---- backbone -------------------------------------------------------------------------------------------------------
+    def _state_version(self):
+        """Sum of the in-place version counters of every parameter and BatchNorm buffer plus their storage addresses: an optimiser
+        step, mst_batchnorm_train's running-statistics update or any weight surgery changes it (the folded weights were
+        keyed on (sum_in, device) only, so an eval forward after training steps reused the backbone folded at the first eval)."""
+        v = 0
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            v += t._version + (t.data_ptr() & 0xFFFF)
+        return v
+
     def _prepare(self, sum_in: bool):
-        key = (sum_in, str(self.device))
+        key = (sum_in, str(self.device), self._state_version())
         if self._prep is not None and self._prep["key"] == key:
             return self._prep
         dev = self.device
@@ -304,8 +313,10 @@ class ResNetSliceTrans(ResNet):
         return super()._apply(fn, *args, **kwargs)
 
     def _fusion_weights(self):
-        if self._fw is not None:
-            return self._fw
+        # (copies exist only where a parameter is not already fp32 on the device; the version sum catches in-place updates of those too)
+        ver = sum(t._version + (t.data_ptr() & 0xFFFF) for t in [self.cls_token, *self.slice_fusion.parameters(), *self.linear.parameters()])
+        if self._fw is not None and self._fw[2] == ver:
+            return self._fw[:2]
         dev = self.device
         keep = []
 
@@ -327,8 +338,8 @@ class ResNetSliceTrans(ResNet):
         fw.lin2_w, fw.lin2_b = f32(lay.linear2.weight), f32(lay.linear2.bias)
         fw.norm_w, fw.norm_b = f32(self.slice_fusion.norm.weight), f32(self.slice_fusion.norm.bias)
         fw.head_w, fw.head_b, fw.head_in = f32(self.linear.weight), f32(self.linear.bias), self.emb_ch
-        self._fw = (fw, keep)
-        return self._fw
+        self._fw = (fw, keep, ver)
+        return self._fw[:2]
 
     def fuse(self, emb: torch.Tensor, B: int, D: int, src_key_padding_mask=None, save_attn: bool = False) -> torch.Tensor:
         """[B*D, 512] slice embeddings -> logits [B, out_ch] (resnet.py:180-191)."""

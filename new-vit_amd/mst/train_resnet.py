@@ -187,6 +187,7 @@ class _ResNetFunction(torch.autograd.Function):
 
 
 def forward_with_grad(model, x_nhwc, sum_in: bool, B=None, D=None, mask=None):
+    model._invalidate()                                  # a training step follows: the BatchNorm-folded inference weights are stale after it
     params = [p for p in model.parameters()]
     for p in params:
         if p.dtype != torch.float32 or p.device.type != "cuda":

@@ -163,6 +163,36 @@ def test_gemm32(hip, M, N, K):
     assert scaled_err(out, _gemm_ref(a, w, bias, 3, None, resid)) < 2e-5
 
 
+def test_gemm_falls_back_for_unaligned_operands(hip):
+    """the weights-in-registers kernel (M >= 8192, K = 384, N % 384 == 0) moves 16-byte pieces on A, W and C; a row
+    pitch that is not a multiple of 8 elements or a pointer off a 16-byte boundary must take the tiled kernels, same results."""
+    M, K, N = 8448, 384, 384
+    a = rnd((M, K), 31).to(torch.bfloat16).cuda()
+    w = (rnd((N, K), 32) / math.sqrt(K)).to(torch.bfloat16).cuda()
+    bias = rnd((N,), 33).cuda()
+    ref = hip.gemm(a, w, bias)
+    # A shifted by 8 bytes (4 elements) inside a larger allocation: same values, misaligned base pointer, aligned pitch
+    big = torch.zeros(M * K + 8, dtype=torch.bfloat16, device="cuda")
+    a2 = big[4:4 + M * K].view(M, K)
+    a2.copy_(a)
+    assert a2.data_ptr() % 16 == 8
+    out = hip.gemm(a2, w, bias)
+    ref64 = _gemm_ref(a.cpu(), w.cpu(), bias.cpu(), 0, None, None)
+    assert scaled_err(out, ref64) < 1e-2                 # the tiled kernels (different summation order than the wreg kernel)
+    assert scaled_err(ref, ref64) < 1e-2
+
+
+def test_colsum_more_row_blocks_than_grid_y(hip):
+    """16.8 M rows (the stem BatchNorm sums of a 2 x 128 x 512^2 ResNet step) are 65,536 blocks of 256 rows -- one more
+    than gridDim.y takes; the row blocks now sit on gridDim.x."""
+    rows, cols = 256 * 65536 + 3, 2
+    a = torch.ones(rows, cols, device="cuda")
+    a[:, 1] = 0.5
+    out = torch.zeros(cols, device="cuda")
+    hip.colsum(a, out)
+    assert torch.allclose(out.cpu(), torch.tensor([float(rows), rows * 0.5]), rtol=1e-6)
+
+
 def test_gemm_rejects_bad_shapes(hip):
     a = torch.zeros(8, 100, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(128, 100, dtype=torch.bfloat16, device="cuda")

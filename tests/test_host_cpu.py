@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in mst_hip.h but not exported"
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
-    assert lib.mst_version() == 200
+    assert lib.mst_version() == 300 == hip.ABI_VERSION
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -256,3 +256,35 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE 4" in r.stderr
+
+
+def test_block_stream_packer_and_layout_helpers_cpu():
+    """Host logic of the single-role block kernel (include/mst_hip.h, mst_block_fused_s): the weight stream holds every weight once,
+    in consumption order and MFMA fragment order; the blocked / image layout helpers are inverse permutations."""
+    import torch
+    from mst import hip
+    E, H = 384, 1536
+    gen = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    wp, bp, w1, b1, w2, b2, lw, lb, ls1, ls2 = r(E, E), r(E), r(H, E), r(H), r(E, H), r(E), r(E), r(E), r(E), r(E)
+    seq, b1f, pbf, b2f = hip.pack_block_seq(wp, bp, ls1, w1, b1, w2, b2, lw, lb, ls2, torch.float32)
+    assert seq.shape == (108, 12288) and b1f.shape == (H,) and pbf.shape == (E,) and b2f.shape == (E,)
+    s = seq.view(108, 24, 64, 8)
+    k8 = lambda p, h, e: 16 * p + 8 * (e >> 2) + 4 * h + (e & 3)
+    # out-projection chunk 3, fragment (t 5, p 1), lane (m 7, h 1), element 2
+    assert float(s[3, 11, 39, 2]) == float(ls1[167] * wp[167, 96 + 16 + 8 + 2])
+    # W1 chunk 0 (element 12) and chunk 2 (element 13 + 2*(2-1)): fragment = k-step 2t+p
+    assert float(s[12, 4, 3, 5]) == float(lw[64 + k8(0, 0, 5)] * w1[3, 64 + k8(0, 0, 5)])
+    assert float(s[15, 4, 3, 5]) == float(lw[64 + k8(0, 0, 5)] * w1[64 + 3, 64 + k8(0, 0, 5)])
+    # W2 chunk 1 (element 14 + 2): fragment (t 2, p 1), lane (m 3, h 1), element 6
+    assert float(s[16, 5, 35, 6]) == float(ls2[67] * w2[67, 32 + k8(1, 1, 6)])
+    assert float(s[107, 5, 35, 6]) == float(ls2[67] * w2[67, 47 * 32 + k8(1, 1, 6)])
+    assert torch.allclose(b1f, b1 + w1 @ lb, atol=1e-5) and torch.equal(pbf, bp * ls1) and torch.equal(b2f, b2 * ls2)
+    # every weight exactly once
+    assert abs(float(seq.abs().sum()) - float((wp * ls1[:, None]).abs().sum() + (w1 * lw[None]).abs().sum() + (w2 * ls2[:, None]).abs().sum())) < 1.0
+    a = r(96, E)
+    assert torch.equal(hip.from_blocked16(hip.to_blocked16(a)), a) and torch.equal(hip.from_image32(hip.to_image32(a)), a)
+    blk = hip.to_blocked16(a).view(3, 24, 64, 8)
+    assert float(blk[1, 5, 7 + 32, 3]) == float(a[32 + 7, 16 * 5 + 8 + 3])          # row 7 of group 1, column 16*5 + 8*1 + 3
+    img = hip.to_image32(a).view(3, 48, 64, 4)
+    assert float(img[2, 9, 11 + 32, 1]) == float(a[64 + 11, 8 * 9 + 4 + 1])

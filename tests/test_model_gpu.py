@@ -308,6 +308,80 @@ def test_slice_sharded_forward_equals_unsharded_two_ranks_one_gpu():
         assert res["roll_err"] < TOL["fp32"][2]
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_graph_replay_equals_eager(mode):
+    """hipGraph replay of the inference forward (small fixed shapes): logits, the attention read-outs and the
+    stored maps are the eager ones bit for bit, for new inputs and after a weight update (the captured graph points into the
+    prepared weight images, so it is dropped with them)."""
+    g = load_golden("b2_mask")
+    mg = build(CASES["b2_mask"], int(g["seed"]), mode, use_graph="1")
+    me = build(CASES["b2_mask"], int(g["seed"]), mode, use_graph="0")
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    shape = tuple(int(v) for v in g["shape"])
+    with torch.no_grad():
+        for it in range(6):                              # calls 1-2 eager, 3 captures, 4+ replay
+            src = synth.synth_volume(shape, int(g["seed"]) + 100 + it)
+            a = mg(src, src_key_padding_mask=mask, save_attn=True)
+            b = me(src, src_key_padding_mask=mask, save_attn=True)
+            assert torch.equal(a, b), it
+            assert torch.equal(mg.get_attention_maps(), me.get_attention_maps()), it
+            assert torch.equal(mg.get_slice_attention(), me.get_slice_attention()), it
+            assert torch.equal(torch.stack(mg.attention_maps), torch.stack(me.attention_maps)), it
+        assert any(e["graph"] is not None for e in mg._graphs.values())
+        # plain call (other key), then a weight update: both models follow
+        for it in range(4):
+            assert torch.equal(mg(src), me(src))
+        for m in (mg, me):
+            m.linear.weight.mul_(1.25)
+            dict(m.named_parameters())["encoder.blocks.0.5.mlp.fc1.weight" if "encoder.blocks.0.5.mlp.fc1.weight" in dict(m.named_parameters())
+                                       else "encoder.blocks.5.mlp.fc1.weight"].mul_(0.9)
+        for it in range(4):
+            assert torch.equal(mg(src, src_key_padding_mask=mask), me(src, src_key_padding_mask=mask)), it
+
+
+def _rccl_worker(port, ret):
+    import os
+    import torch.distributed as dist
+    # dmabuf IPC is the only mode the host driver supports; without it RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)                 # backend "nccl" IS RCCL on ROCm
+    g = load_golden("b2_mask")
+    model = build(CASES["b2_mask"], int(g["seed"]), "fp16")
+    src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)
+    mask = torch.from_numpy(g["src_key_padding_mask"])
+    res = {}
+    with torch.no_grad():
+        ref = model(src, src_key_padding_mask=mask, save_attn=True)
+        ref_maps = model.get_attention_maps()
+        model.enable_slice_sharding()                                      # the product class: SliceSharding over the default (RCCL) group
+        res["backend"] = dist.get_backend()
+        out = model(src, src_key_padding_mask=mask, save_attn=True)
+        res["logits"] = bool(torch.equal(out, ref))
+        res["maps"] = bool(torch.equal(model.get_attention_maps(), ref_maps))
+        t = torch.tensor([1.0, 5.0, 3.0], device="cuda")
+        res["max"] = bool(torch.equal(model._sharding.all_reduce_max(t.clone()), t))
+    torch.cuda.synchronize()
+    ret[0] = res
+    dist.destroy_process_group()
+
+
+def test_slice_sharding_over_rccl_world_size_one():
+    """every other multi-rank test uses gloo or the host-staged rehearsal transport, so
+    SliceSharding._all_gather on DEVICE tensors over backend "nccl" (= RCCL) had never executed.  A one-GPU box cannot hold two
+    RCCL ranks (duplicate devices are refused), but world_size 1 runs the real all_gather_into_tensor path end to end."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(29541, ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    res = ret[0]
+    assert res["backend"] == "nccl"
+    assert res["logits"] and res["maps"] and res["max"], res
+
+
 def test_full_bench_batch_matches_single_volume_and_reference_fixture():
     """BASELINE configs[1] at full size: 4 x 64 x 518^2 in bf16, one launch sequence over 350,720 tokens.  Volume 0 is the
     input of the reference fixture c3_1x64x518: its logits / embeddings inside the batch must be bit-equal to the

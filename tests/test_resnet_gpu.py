@@ -241,6 +241,38 @@ def test_training_step_matches_autograd_of_oracle(shape, masked, model):
         err.append(rel_l2(p.grad.cpu(), ref_grads[k]))
         noise.append(rel_l2(g32[k], ref_grads[k]))
     assert max(err) < 0.1 and float(np.median(err)) < 0.05, (max(err), float(np.median(err)), max(noise), float(np.median(noise)))
+    # Well-conditioned checks on top of the smoke bar above.
+    # (1) The LAST stage (head, slice transformer, class token, layer4) sees no ReLU-flip amplification behind it: tight bar.
+    last = [k for k in ref_grads if k.startswith(("linear.", "slice_fusion.", "cls_token")) or ".layer4." in k]
+    assert len(last) > 20
+    worst_last = max(float((dict(m.named_parameters())[k].grad.cpu().double() - ref_grads[k]).abs().max()) / max(float(ref_grads[k].abs().max()), 1e-30) for k in last)
+    assert worst_last < 5e-3, worst_last
+    # (2) Directional derivatives: <grad_HIP, v> against a central finite difference of the fp64 oracle LOSS along random parameter
+    # directions.  A single ReLU flip changes one gradient entry by O(1/N) but the loss by O(eps^2): the inner product averages
+    # over ~2e7 entries, so a wrong BatchNorm momentum term or a mis-scaled shortcut gradient (O(1) on whole tensors) shows at the
+    # 1e-2 bar while flips do not.
+    from oracle import resnet_oracle as R
+    names = [k for k, _ in m.named_parameters()]
+    gen = torch.Generator().manual_seed(7)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+    def loss_at(shift):
+        s2 = dict(sd64)
+        for k, dv in shift.items():
+            s2[k] = sd64[k] + dv
+        with torch.no_grad():
+            return float(torch.nn.functional.cross_entropy(R.forward_slice_trans(s2, src.double(), mask, model, train=True)["logits"], target))
+
+    for trial in range(8):
+        # direction: per-tensor normalised noise on a random third of the parameter tensors (so every stage is hit over the trials)
+        pick = [k for k in names if float(torch.rand((), generator=gen)) < 0.34] or names[:1]
+        v = {k: torch.randn(sd64[k].shape, generator=gen, dtype=torch.float64) * float(sd64[k].abs().mean() + 1e-3) for k in pick}
+        eps = 1e-4
+        fd = (loss_at({k: eps * d for k, d in v.items()}) - loss_at({k: -eps * d for k, d in v.items()})) / (2 * eps)
+        dd_hip = sum(float((dict(m.named_parameters())[k].grad.cpu().double() * v[k]).sum()) for k in pick)
+        dd_ref = sum(float((ref_grads[k] * v[k]).sum()) for k in pick)
+        assert abs(dd_ref - fd) <= 2e-3 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_ref, fd)          # the oracle's own autograd is consistent
+        assert abs(dd_hip - fd) <= 1e-2 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_hip, fd)
     # running statistics as nn.BatchNorm2d updates them in train mode
     for k, v in m.state_dict().items():
         if "running_" in k:
@@ -256,9 +288,15 @@ def test_training_loss_goes_down_with_adamw():
         warnings.simplefilter("ignore")
         m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=18)
     m.load_state_dict(synth.synth_resnet_state_dict(3, 18, 2), strict=True)
-    m = m.cuda().train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    from oracle import resnet_oracle as R
+    m = m.cuda()
     src = synth.synth_volume((2, 1, 4, 64, 64), 77)
+    # the reference Trainer validates BEFORE and BETWEEN training epochs (main_train.py:110-123: num_sanity_val_steps=2,
+    # check_val_every_n_epoch=1): an eval forward first, so that the BatchNorm-folded inference weights exist when training starts
+    with torch.no_grad():
+        before = m.eval()(src).clone()
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
     target = torch.tensor([0, 1]).cuda()
     losses = []
     for _ in range(6):
@@ -268,3 +306,11 @@ def test_training_loss_goes_down_with_adamw():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+    # ... and the eval forward AFTER the optimiser steps runs on the updated parameters and running statistics (the folded
+    # backbone used to be cached on (sum_in, device) only): it must match the oracle on the model's current state_dict
+    with torch.no_grad():
+        after = m.eval()(src)
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        ref = R.forward_slice_trans(sd, src, None, model=18)
+    assert float((after.cpu() - ref["logits"]).abs().max()) < 1e-3 * max(1.0, float(ref["logits"].abs().max()))
+    assert float((after - before).abs().max()) > 1e-3      # the six steps did move the logits: a stale cache would reproduce `before`

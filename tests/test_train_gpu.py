@@ -111,7 +111,11 @@ def test_features_path_frozen_encoder_and_an_optimizer_step():
             r = ref2[k]
             assert float((p.grad.cpu() - r).abs().max()) <= 1e-3 * float(r.abs().max()) + 1e-9, k
     # AdamW (dino.py:41) on the HIP gradients lowers the loss
-    model = build({}, int(g["seed"]), "fp32").train()
+    from oracle import mst_oracle as O
+    model = build({}, int(g["seed"]), "fp32")
+    with torch.no_grad():                                # an eval forward first: the prepared weight images exist when training starts
+        before = model.eval()(src, src_key_padding_mask=mask).clone()
+    model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
     losses = []
     for _ in range(3):
@@ -121,9 +125,25 @@ def test_features_path_frozen_encoder_and_an_optimizer_step():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
-    with torch.no_grad():                                # and the inference path sees the updated weights
-        model.eval()
-        assert torch.isfinite(model(src, src_key_padding_mask=mask)).all()
+    with torch.no_grad():                                # and the inference path sees the updated weights: oracle on the CURRENT state_dict
+        after = model.eval()(src, src_key_padding_mask=mask)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        ref = O.forward(sd, src, src_key_padding_mask=mask)["logits"]
+    assert float((after.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((after - before).abs().max()) > 1e-5
+    # an in-place edit of ONE parameter that is none of the first / last / third-point tensors, under no_grad (weight surgery): the
+    # prepared images must follow (the signature used to look at four sentinel tensors only)
+    for dtname, tol in (("fp32", 1e-4), ("bf16", 3e-2)):
+        m2 = build({}, int(g["seed"]), dtname).eval()
+        with torch.no_grad():
+            m2(src, src_key_padding_mask=mask)
+            names = [k for k, _ in m2.named_parameters()]
+            victim = dict(m2.named_parameters())[names[len(names) // 2 + 3]]
+            victim.mul_(1.5)
+            got = m2(src, src_key_padding_mask=mask)
+            sd2 = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+            ref2 = O.forward(sd2, src, src_key_padding_mask=mask)["logits"]
+        assert float((got.cpu() - ref2).abs().max()) < tol * max(1.0, float(ref2.abs().max())), dtname
 
 
 def _ddp_worker(rank, world, port, ret):

@@ -11,3 +11,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.json
 cat $OUT/summary.json
+# prune bulky raw outputs (gpurun copies back at most 64 MiB): keep the summaries, the per-kernel stats and the bench line
+find $OUT -type f \( -name "*.db" -o -name "*_kernel_trace.csv" -o -name "*counter_collection.csv" -o -name "*agent_info.csv" -o -name "*.pftrace" \) -delete 2>/dev/null || true
