@@ -205,9 +205,10 @@ class DinoV2ClassifierSlice(BasicClassifier):
         # opt-in (default off: every block computes every token, as the reference does): the last block computes only what is read
         # behind it -- K/V of every token and the attention + MLP of the class tokens; results are the reference's
         prune_last_block = bool(int(kwargs.pop("prune_last_block", os.environ.get("MST_PRUNE_LAST_BLOCK", 0))))
-        # hipGraph replay of the inference forward for small fixed shapes (launch-bound: ~90 launches of 5-10 us each at 16 x 224^2).
-        # "auto": calls of at most MST_GRAPH_MAX_TOKENS tokens; 0 / 1 force it off / on.  Results are the eager ones bit for bit.
-        use_graph = str(kwargs.pop("use_graph", os.environ.get("MST_USE_GRAPH", "auto"))).lower()
+        # hipGraph replay of the inference forward for small fixed shapes.  OPT-IN ("1"; "auto" = calls of at most MST_GRAPH_MAX_TOKENS
+        # tokens): measured on the MI355X box the 16 x 224^2 forward takes 1.083 ms eager and 1.082 ms replayed -- the ~90 launches are
+        # not the bound, the under-filled kernels are (profiles/r04d_small_shapes.txt).  Results are the eager ones bit for bit.
+        use_graph = str(kwargs.pop("use_graph", os.environ.get("MST_USE_GRAPH", "0"))).lower()
         if compute_dtype not in hip.DT_NAMES:
             raise ValueError(f"compute_dtype must be one of {sorted(hip.DT_NAMES)}")
         super().__init__(in_ch, out_ch, spatial_dims=spatial_dims, optimizer_kwargs=optimizer_kwargs, **kwargs)
@@ -622,14 +623,12 @@ class DinoV2ClassifierSlice(BasicClassifier):
         key = (tuple(x.shape), x.dtype, bool(save_attn), mask is not None, without_linear, id(prep), torch.cuda.current_device())
         ent = self._graphs.get(key)
         if ent is None or ent["graph"] is None:
-            out = self._forward_eager(x, save_attn, mask, kwargs)
             if ent is None:
-                self._graphs[key] = {"graph": None, "calls": 1}
-                return out
+                ent = self._graphs[key] = {"graph": None, "calls": 0}
             ent["calls"] += 1
             if ent["calls"] < 3:
-                return out
-            # capture on a side stream, as torch.cuda.graph does; static copies of the inputs
+                return self._forward_eager(x, save_attn, mask, kwargs)
+            # capture (nothing executes while capturing: the replay below produces this call's results); static copies of the inputs
             sx = x.clone()
             sm = None if mask is None else mask.to(self.device).clone()
             torch.cuda.synchronize()
@@ -640,9 +639,8 @@ class DinoV2ClassifierSlice(BasicClassifier):
                     state = (self.attention_maps, self.attention_maps_slice, getattr(self, "_cls_last", None)) if save_attn else None
             except Exception:
                 self._graphs[key] = {"graph": None, "calls": -(1 << 30)}     # this key stays eager
-                return out
+                return self._forward_eager(x, save_attn, mask, kwargs)
             ent.update(graph=g, x=sx, mask=sm, out=sout, state=state)
-            return out
         ent["x"].copy_(x)
         if ent["mask"] is not None:
             ent["mask"].copy_(mask)

@@ -267,11 +267,12 @@ def test_training_step_matches_autograd_of_oracle(shape, masked, model):
         # direction: per-tensor normalised noise on a random third of the parameter tensors (so every stage is hit over the trials)
         pick = [k for k in names if float(torch.rand((), generator=gen)) < 0.34] or names[:1]
         v = {k: torch.randn(sd64[k].shape, generator=gen, dtype=torch.float64) * float(sd64[k].abs().mean() + 1e-3) for k in pick}
-        eps = 1e-4
+        eps = 1e-7                                       # the loss is piecewise smooth: the difference quotient's error is proportional to the
         fd = (loss_at({k: eps * d for k, d in v.items()}) - loss_at({k: -eps * d for k, d in v.items()})) / (2 * eps)
         dd_hip = sum(float((dict(m.named_parameters())[k].grad.cpu().double() * v[k]).sum()) for k in pick)
         dd_ref = sum(float((ref_grads[k] * v[k]).sum()) for k in pick)
-        assert abs(dd_ref - fd) <= 2e-3 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_ref, fd)          # the oracle's own autograd is consistent
+        # ReLU / max-pool kinks inside +-eps (measured on this case: 1.1e-2 at 1e-4, 2.7e-4 at 1e-6, 1.7e-8 at 1e-7)
+        assert abs(dd_ref - fd) <= 1e-4 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_ref, fd)          # the oracle's own autograd is consistent
         assert abs(dd_hip - fd) <= 1e-2 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_hip, fd)
     # running statistics as nn.BatchNorm2d updates them in train mode
     for k, v in m.state_dict().items():
