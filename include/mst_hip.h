@@ -54,7 +54,7 @@ const char* mst_last_error(void); /* thread-local message of the last failing ca
 
 /* nn.LayerNorm over the last dim: block.py:63,75; vision_transformer.py:165,263 (eps 1e-6);
  * transformer_blocks.py:499-500, dino.py:95 (eps 1e-5).  x fp32 [rows, cols] with row stride
- * x_stride (elements); out dtype f32/f16/bf16 with row stride out_stride.  cols even, <= 1024.
+ * x_stride (elements); out dtype f32/f16/bf16 with row stride out_stride.  cols even, <= 2048.
  * gamma == beta == NULL: normalise only (the affine is folded into the consumer's weights). */
 int mst_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta,
                   void* out, int out_dtype, int64_t out_stride, int64_t rows, int cols, float eps,
@@ -244,7 +244,7 @@ int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, c
  * mst_softmax_rows: S [rows, L] -> softmax over L in place; mask (nullable) uint8 [rows / rows_per_batch, L], 1 = key
  *   ignored (src_key_padding_mask, transformer_blocks.py:244-252).  mst_softmax_rows_bwd: dP <- scale * P o (dP - rowsum(dP o P)).
  * mst_layernorm_bwd: dx[r] = (dres ? dres[r] : 0) + LayerNorm'(x[r]; gamma) . dy[r]; dgamma[c] += sum_r dy xhat, dbeta[c] += sum_r dy
- *   (dx, dres, dgamma, dbeta, gamma nullable; row strides in elements; cols <= 1024; accumulation by fp32 atomics).
+ *   (dx, dres, dgamma, dbeta, gamma nullable; row strides in elements; cols <= 2048; accumulation by fp32 atomics).
  * mst_act_fwd / mst_act_bwd: kind 0 GELU (erf form, mlp.py:22), 1 ReLU; bwd: dy <- dy * act'(h) in place.
  * mst_colsum: out[c] += sum_r a[r][c] * (b ? b[r][c] : 1)   (bias and LayerScale gradients).
  * mst_axpby_cols: y[r][c] = alpha * x[r][c] * (g ? g[c] : 1) + beta * y[r][c].

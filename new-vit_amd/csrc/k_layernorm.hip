@@ -73,13 +73,14 @@ static int launch_ln_t(const float* x, int64_t xs, const float* g, const float* 
     if (nj <= 1) layernorm_kernel<1, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
     else if (nj <= 3) layernorm_kernel<3, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
     else if (nj <= 6) layernorm_kernel<6, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
-    else layernorm_kernel<8, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else if (nj <= 8) layernorm_kernel<8, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);
+    else layernorm_kernel<16, OutT><<<grid, block, 0, s>>>(x, xs, g, b, o, os, rows, cols, eps);     // 2048: the slice transformer behind a bottleneck ResNet
     return mst_check_launch("layernorm");
 }
 
 int launch_layernorm(const float* x, int64_t xs, const float* g, const float* b, void* out, int odt,
                      int64_t os, int64_t rows, int cols, float eps, hipStream_t s) {
-    MST_CHECK_ARG(cols > 0 && cols <= 1024 && (cols % 2) == 0, "layernorm: cols=%d must be even and <= 1024", cols);
+    MST_CHECK_ARG(cols > 0 && cols <= 2048 && (cols % 2) == 0, "layernorm: cols=%d must be even and <= 2048", cols);
     MST_CHECK_ARG((xs % 2) == 0 && (os % 2) == 0, "layernorm: row strides must be even");
     if (rows <= 0) return MST_OK;
     switch (odt) {

@@ -278,8 +278,8 @@ int launch_slice_attn(const float* qkv, int B, int L, int heads, int hd, const u
         break;                                                                                                   \
     }
     switch (hd) {
-        SA_CASE(4) SA_CASE(8) SA_CASE(16) SA_CASE(32) SA_CASE(64)
-        default: mst_set_error("slice_attn: head_dim=%d unsupported (4,8,16,32,64)", hd); return MST_EINVAL;
+        SA_CASE(4) SA_CASE(8) SA_CASE(16) SA_CASE(32) SA_CASE(64) SA_CASE(128)     // 128: 16 heads over the 2048-wide embeddings of a bottleneck ResNet
+        default: mst_set_error("slice_attn: head_dim=%d unsupported (4,8,16,32,64,128)", hd); return MST_EINVAL;
     }
 #undef SA_CASE
     return mst_check_launch("slice_attn");

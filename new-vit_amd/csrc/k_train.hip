@@ -298,13 +298,14 @@ int launch_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, floa
 
 int launch_layernorm_bwd(const float* x, int64_t xs, const float* gamma, const float* dy, int64_t dys, const float* dres, int64_t drs,
                          float* dx, int64_t dxs, float* dgamma, float* dbeta, int64_t rows, int cols, float eps, hipStream_t s) {
-    MST_CHECK_ARG(cols > 0 && cols <= 1024, "layernorm_bwd: cols=%d unsupported (<= 1024)", cols);
+    MST_CHECK_ARG(cols > 0 && cols <= 2048, "layernorm_bwd: cols=%d unsupported (<= 2048)", cols);
     const unsigned grid = (unsigned)(rows < 4 ? 1 : (rows / 4 < 2048 ? rows / 4 : 2048));
 #define LNB(CI) layernorm_bwd_kernel<CI><<<dim3(grid), dim3(256), 0, s>>>(x, xs, gamma, dy, dys, dres, drs, dx, dxs, dgamma, dbeta, rows, cols, eps)
     if (cols <= 128) LNB(2);
     else if (cols <= 384) LNB(6);
     else if (cols <= 768) LNB(12);
-    else LNB(16);
+    else if (cols <= 1024) LNB(16);
+    else LNB(32);
 #undef LNB
     return mst_check_launch("layernorm_bwd");
 }

@@ -21,7 +21,8 @@ fixture of the reference's own ``TransformerEncoderLayer`` (tests/golden/resnet_
   Grad-CAM++ ``save_attn=True`` (resnet.py:62-118): the map of the LAST ReLU output -- the one ``get_attention_maps`` returns --
              by ``mst_gradcampp``; the maps of the earlier ReLUs, which the reference computes and never exposes, are not produced.
 
-Not built (raise): the MONAI branches (3-D, and ``pretrained=False`` in the reference), bottleneck ResNets (model >= 50), a
+Bottleneck ResNets (model 50 / 101 / 152: 2048-wide slice embeddings, 16 heads of 128) run through the same kernels (round 3).
+Not built (raise): the MONAI branches (3-D, and ``pretrained=False`` in the reference), a
 backward pass through eval-mode BatchNorm (gradients with ``model.eval()``).  ``pretrained=True`` needs torchvision's weights (network / hub cache); when torchvision is absent the tree
 is initialised like torchvision's and a warning says so -- a checkpoint's ``state_dict`` replaces it anyway.
 """
@@ -37,7 +38,7 @@ import torch.nn as nn
 from .base_model import BasicClassifier
 from .. import hip
 
-_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 _WIDTHS = [64, 128, 256, 512]
 
 
@@ -83,20 +84,39 @@ class _BasicBlock(_P):
             self.downsample = nn.ModuleList([_Conv(cin, cout, 1), _BN(cout)])       # keys downsample.0.* / downsample.1.*
 
 
+class _Bottleneck(_P):
+    """torchvision Bottleneck (v1.5): 1x1 -> 3x3 (carries the stride) -> 1x1 (x4), each with its BatchNorm (models 50 / 101 / 152:
+    reference resnet.py:44-50 takes whichever torchvision model `model` names; emb_ch 2048, resnet.py:152)."""
+
+    def __init__(self, cin, w, stride):
+        super().__init__()
+        self.conv1, self.bn1 = _Conv(cin, w, 1), _BN(w)
+        self.conv2, self.bn2 = _Conv(w, w, 3), _BN(w)
+        self.conv3, self.bn3 = _Conv(w, 4 * w, 1), _BN(4 * w)
+        self.stride = stride
+        if stride != 1 or cin != 4 * w:
+            self.downsample = nn.ModuleList([_Conv(cin, 4 * w, 1), _BN(4 * w)])
+
+
 class _TVResNet(_P):
-    """Parameter tree of torchvision.models.resnet{18,34} (keys conv1, bn1, layer1..4.<i>.*, fc)."""
+    """Parameter tree of torchvision.models.resnet{18,34,50,101,152} (keys conv1, bn1, layer1..4.<i>.*, fc)."""
 
     def __init__(self, model: int, fc_out: Optional[int]):
         super().__init__()
         if model not in _LAYERS:
-            raise NotImplementedError(f"resnet{model}: only the BasicBlock models (18, 34) are built on the HIP path")
+            raise NotImplementedError(f"resnet{model}: torchvision's resnet 18 / 34 / 50 / 101 / 152 are built on the HIP path")
         self.conv1, self.bn1 = _Conv(3, 64, 7), _BN(64)
         cin = 64
         for li, (n, w) in enumerate(zip(_LAYERS[model], _WIDTHS)):
             blocks = []
             for b in range(n):
-                blocks.append(_BasicBlock(cin, w, 2 if (b == 0 and li > 0) else 1))
-                cin = w
+                stride = 2 if (b == 0 and li > 0) else 1
+                if model >= 50:
+                    blocks.append(_Bottleneck(cin, w, stride))
+                    cin = 4 * w
+                else:
+                    blocks.append(_BasicBlock(cin, w, stride))
+                    cin = w
             setattr(self, f"layer{li + 1}", nn.ModuleList(blocks))
         self.out_features = cin
         self.fc = nn.Identity() if fc_out is None else _Linear(cin, fc_out)
@@ -173,6 +193,8 @@ class ResNet(BasicClassifier):
         for li in range(4):
             for blk in getattr(m, f"layer{li + 1}"):
                 e = {"stride": blk.stride, "c1": _fold(blk.conv1, blk.bn1, False, dev), "c2": _fold(blk.conv2, blk.bn2, False, dev)}
+                if hasattr(blk, "conv3"):
+                    e["c3"] = _fold(blk.conv3, blk.bn3, False, dev)
                 if hasattr(blk, "downsample"):
                     e["ds"] = _fold(blk.downsample[0], blk.downsample[1], False, dev)
                 prep["blocks"].append(e)
@@ -199,6 +221,20 @@ class ResNet(BasicClassifier):
                 s = e["stride"]
                 Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
                 w1, b1, k1 = e["c1"]
+                if "c3" in e:                            # bottleneck: 1x1 -> 3x3 (stride) -> 1x1, the residual joins after the third
+                    h0 = hip.gemm(hip.im2col_nhwc(y, 1, 1, 1, 0, k1), w1, b1, epilogue=hip.EPI_BIAS_RELU).view(n, H, W, w1.shape[0])
+                    w2, b2, k2 = e["c2"]
+                    h1 = hip.gemm(hip.im2col_nhwc(h0, 3, 3, s, 1, k2), w2, b2, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w2.shape[0])
+                    if "ds" in e:
+                        wd, bd, kd = e["ds"]
+                        idt = hip.gemm(hip.im2col_nhwc(y, 1, 1, s, 0, kd), wd, bd, epilogue=hip.EPI_BIAS)
+                    else:
+                        idt = y.reshape(n * H * W, Cin).clone()
+                    w3, b3, k3 = e["c3"]
+                    hip.gemm(hip.im2col_nhwc(h1, 1, 1, 1, 0, k3), w3, b3, epilogue=hip.EPI_RESIDUAL, out=idt)
+                    hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))
+                    y = idt.view(n, Ho, Wo, w3.shape[0])
+                    continue
                 h1 = hip.gemm(hip.im2col_nhwc(y, 3, 3, s, 1, k1), w1, b1, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w1.shape[0])
                 if "ds" in e:
                     wd, bd, kd = e["ds"]

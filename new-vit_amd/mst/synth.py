@@ -177,7 +177,7 @@ def state_dict_digest(sd) -> str:
     return h.hexdigest()
 
 
-_RESNET_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_RESNET_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
 def synth_resnet_state_dict(seed: int = 0, model: int = 34, out_ch: int = 2, slice_trans: bool = True,
@@ -200,19 +200,30 @@ def synth_resnet_state_dict(seed: int = 0, model: int = 34, out_ch: int = 2, sli
     conv("model.conv1", 64, 3, 7)
     bn("model.bn1", 64)
     cin = 64
+    bottleneck = model >= 50                             # torchvision Bottleneck (v1.5: the stride sits on the 3x3 convolution), expansion 4
     for li, (n, w) in enumerate(zip(_RESNET_LAYERS[model], (64, 128, 256, 512))):
         for b in range(n):
             p = f"model.layer{li + 1}.{b}"
             stride = 2 if (b == 0 and li > 0) else 1
-            conv(p + ".conv1", w, cin, 3)
-            bn(p + ".bn1", w)
-            conv(p + ".conv2", w, w, 3)
-            bn(p + ".bn2", w)
-            if stride != 1 or cin != w:
-                conv(p + ".downsample.0", w, cin, 1)
-                bn(p + ".downsample.1", w)
-            cin = w
-    E = 512
+            if bottleneck:
+                conv(p + ".conv1", w, cin, 1)
+                bn(p + ".bn1", w)
+                conv(p + ".conv2", w, w, 3)
+                bn(p + ".bn2", w)
+                conv(p + ".conv3", 4 * w, w, 1)
+                bn(p + ".bn3", 4 * w)
+                cout = 4 * w
+            else:
+                conv(p + ".conv1", w, cin, 3)
+                bn(p + ".bn1", w)
+                conv(p + ".conv2", w, w, 3)
+                bn(p + ".bn2", w)
+                cout = w
+            if stride != 1 or cin != cout:
+                conv(p + ".downsample.0", cout, cin, 1)
+                bn(p + ".downsample.1", cout)
+            cin = cout
+    E = cin                                              # 512 (BasicBlock models) or 2048 (reference resnet.py:152)
 
     def lin(k, out_f, in_f, gain=1.0):
         sd[k + ".weight"] = _t(k + ".weight", (out_f, in_f), seed, gain / math.sqrt(in_f))

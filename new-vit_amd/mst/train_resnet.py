@@ -98,7 +98,7 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
 
 
 def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool):
-    """torchvision resnet{18,34} forward in train mode up to the pooled features [n, 512]."""
+    """torchvision resnet{18,34,50,101,152} forward in train mode up to the pooled features [n, 512 or 2048]."""
     sv = {"units": []}
     y, sv["stem"] = _conv_bn_fwd(x_nhwc.contiguous(), m.conv1, m.bn1, 7, 2, 3, sum_in, None, True)
     sv["pool_in"] = y
@@ -106,6 +106,18 @@ def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool):
     for li in range(4):
         for blk in getattr(m, f"layer{li + 1}"):
             n, H, W, Cin = y.shape
+            if hasattr(blk, "conv3"):                                    # bottleneck: 1x1 -> 3x3 (stride) -> 1x1 + residual
+                h0, r0 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 1, 1, 0, False, None, True)
+                h1, r1 = _conv_bn_fwd(h0, blk.conv2, blk.bn2, 3, blk.stride, 1, False, None, True)
+                rd = None
+                if hasattr(blk, "downsample"):
+                    idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False)
+                    idt = idt.reshape(-1, idt.shape[-1])
+                else:
+                    idt = y.reshape(n * H * W, Cin)
+                y, r2 = _conv_bn_fwd(h1, blk.conv3, blk.bn3, 1, 1, 0, False, idt, True)
+                sv["units"].append((r0, r2, rd, r1))
+                continue
             h1, r1 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 3, blk.stride, 1, False, None, True)
             rd = None
             if hasattr(blk, "downsample"):
@@ -114,7 +126,7 @@ def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool):
             else:
                 idt = y.reshape(n * H * W, Cin)
             y, r2 = _conv_bn_fwd(h1, blk.conv2, blk.bn2, 3, 1, 1, False, idt, True)
-            sv["units"].append((r1, r2, rd))
+            sv["units"].append((r1, r2, rd, None))
     sv["last"] = y
     return hip.avgpool_nhwc(y), sv
 
@@ -123,8 +135,10 @@ def backbone_bwd(G: _Grads, sv, dfeat: torch.Tensor):
     y = sv["last"]
     n, H, W, Cc = y.shape
     dy = hip.avgpool_bwd_nhwc(dfeat.contiguous(), H * W).view(n * H * W, Cc)
-    for r1, r2, rd in reversed(sv["units"]):
+    for r1, r2, rd, rmid in reversed(sv["units"]):
         dh1 = _conv_bn_bwd(G, r2, dy, True)                               # dy now carries the ReLU mask of the block output
+        if rmid is not None:                                              # bottleneck: through the 3x3 unit to the first 1x1's output
+            dh1 = _conv_bn_bwd(G, rmid, dh1.view(-1, dh1.shape[-1]), True)
         xin = r1["x"]
         if rd is not None:
             dx = _conv_bn_bwd(G, rd, dy.clone(), True)

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import mst_oracle as O
 
 SD = Dict[str, torch.Tensor]
-_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3]}
+_LAYERS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
 
 _TRAIN = False
@@ -54,8 +54,13 @@ def _resnet_features(sd: SD, x: torch.Tensor, model: int, prefix: str, last: Opt
             q = f"{p}layer{li + 1}.{b}"
             stride = 2 if (b == 0 and li > 0) else 1
             idt = y
-            out = F.relu(_bn(sd, q + ".bn1", F.conv2d(y, sd[q + ".conv1.weight"], stride=stride, padding=1)))
-            out = _bn(sd, q + ".bn2", F.conv2d(out, sd[q + ".conv2.weight"], stride=1, padding=1))
+            if q + ".conv3.weight" in sd:                # torchvision Bottleneck (v1.5): 1x1 -> 3x3 (carries the stride) -> 1x1 (x4)
+                out = F.relu(_bn(sd, q + ".bn1", F.conv2d(y, sd[q + ".conv1.weight"])))
+                out = F.relu(_bn(sd, q + ".bn2", F.conv2d(out, sd[q + ".conv2.weight"], stride=stride, padding=1)))
+                out = _bn(sd, q + ".bn3", F.conv2d(out, sd[q + ".conv3.weight"]))
+            else:                                        # BasicBlock
+                out = F.relu(_bn(sd, q + ".bn1", F.conv2d(y, sd[q + ".conv1.weight"], stride=stride, padding=1)))
+                out = _bn(sd, q + ".bn2", F.conv2d(out, sd[q + ".conv2.weight"], stride=1, padding=1))
             if q + ".downsample.0.weight" in sd:
                 idt = _bn(sd, q + ".downsample.1", F.conv2d(y, sd[q + ".downsample.0.weight"], stride=stride))
             y = F.relu(out + idt)
