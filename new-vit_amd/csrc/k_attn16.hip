@@ -325,6 +325,21 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 }
             }
             float lsum = 0.f;
+#ifdef ATTN_PK_SUM
+            // row sums by packed adds (v_pk_add_f32: two values per instruction): 16 instead of 32 vector instructions per tile
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                    s[kb][r] = p0;
+                    s[kb][r + 1] = p1;
+                    l2 += f32x2{p0, p1};
+                }
+            lsum = l2[0] + l2[1];
+#else
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -340,6 +355,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                     lsum += p;                           // one chain: four partial sums measured 3 % slower (registers)
 #endif
                 }
+#endif
             l_run += lsum;
             vec8 pf[4];
 #pragma unroll

@@ -242,9 +242,22 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
                 lds_read_b128_acc<64>(bt2, baddr);
                 lds_read_b128_acc<96>(bt3, baddr);
             }
+#ifdef BLOCKS_WAIT2
+            // ONE counted wait per two slots: at an even slot fragments i and i + 1 have landed once only the reads behind
+            // fragment i + 1 are outstanding (fragments i + 2 .. last issued, plus the four b1 reads where they are younger)
+            if constexpr (i % 2 == 0) {
+                constexpr int last = TAIL ? i + D : (i + D < NF - 1 ? i + D : NF - 1);
+                constexpr int younger_frags = last - (i + 1) > 0 ? last - (i + 1) : 0;
+                constexpr int younger_bias = (BQ >= 0 && i >= BIAS_SLOT && i + 1 <= BIAS_SLOT + D) ? 4 : 0;
+                wait_lgkm<younger_frags + younger_bias>();
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             constexpr int younger_frags = TAIL ? D : (NF - 1 - i < D ? NF - 1 - i : D);
             constexpr int younger_bias = (BQ >= 0 && i >= BIAS_SLOT && i <= BIAS_SLOT + D) ? 4 : 0;
             wait_lgkm<younger_frags + younger_bias>();
+#endif
             if constexpr (BQ >= 0 && i == BIAS_SLOT + D + 1) {
                 // this slot's counted wait covers the four b1 reads: only now do the values exist for hipcc (an asm output it may
                 // copy at once -- it moved the in-flight registers into the accumulator file right behind the reads otherwise)

@@ -2,6 +2,8 @@
 The across-slice half is checked against a fixture the reference's own TransformerEncoderLayer(512, nhead 16) produced
 (tests/golden/resnet_fusion.npz); the torchvision backbone is not in the reference tree, so its parity is against the restated
 architecture of oracle/resnet_oracle.py (UNPINNED), fp32, relative 1e-4."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -403,3 +405,40 @@ def test_training_loss_goes_down_with_adamw():
         ref = R.forward_slice_trans(sd, src, None, model=18)
     assert float((after.cpu() - ref["logits"]).abs().max()) < 1e-3 * max(1.0, float(ref["logits"].abs().max()))
     assert float((after - before).abs().max()) > 1e-3      # the six steps did move the logits: a stale cache would reproduce `before`
+
+
+def test_full_config3_shape_training_step_properties():
+    """BASELINE configs[3] at its full per-GPU size: one ResNetSliceTrans(resnet34) training step on a 1 x 128 x 512 x 512 volume
+    (128 images through the backbone with batch statistics over all of them, ~28 GiB of saved activations).  The fp64 oracle does
+    not finish at this size, so size-independent properties: a finite loss and a finite, non-zero gradient for every parameter; a
+    second identical step from the same weights reproduces the loss to 1e-4 (the atomically accumulated sums reorder); the
+    BatchNorm counters moved by exactly one step; one AdamW step on those gradients lowers the loss on the same volume; peak
+    memory stays under 40 GiB.  The arithmetic itself is pinned at small sizes above."""
+    import warnings
+    from mst.models import ResNetSliceTrans
+    sd = synth.synth_resnet_state_dict(61, 34, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    src = synth.synth_volume((1, 1, 128, 512, 512), 62)
+    target = torch.tensor([1]).cuda()
+    losses = []
+    for rep in range(2):
+        m.load_state_dict(sd, strict=True)
+        m.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(src), target)
+        loss.backward()
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1])
+        for k, p in m.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, k
+        assert int(m.state_dict()["model.bn1.num_batches_tracked"]) == 1
+    assert abs(losses[0] - losses[1]) < 1e-4 * max(1.0, abs(losses[0])), losses
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    opt.step()
+    with torch.no_grad():
+        after = float(torch.nn.functional.cross_entropy(m.train()(src), target))
+    assert after < losses[1], (after, losses)
+    assert torch.cuda.max_memory_allocated() < 40 * 2 ** 30
