@@ -172,8 +172,7 @@ def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], wit
     if model.rotary is not None:
         raise NotImplementedError("training step: rotary variants of the slice transformer are not on the HIP backward yet")
     enc = model.encoder
-    if enc.num_register_tokens:
-        raise NotImplementedError("training step: register tokens are not on the HIP backward yet")
+    R = int(enc.num_register_tokens)                     # register tokens (vision_transformer.py:222-230): extra prefix rows without a position
     dev = model.device
     x = source.to(dev)
     B, C, D0, H, W = x.shape
@@ -188,17 +187,25 @@ def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], wit
     n = B * D
     gh, gw = H // PATCH, W // PATCH
     Np = gh * gw
-    N = 1 + Np
+    N = 1 + R + Np
     M = n * N
+    sv["R"] = R
     # ---- tokens (patch_embed.py:68-81; vision_transformer.py:213-232)
     pos = enc.pos_embed.detach()[0]
     n_stored = pos.shape[0] - 1
     Mg = int(math.isqrt(n_stored))
     sv["interp"] = not (Np == n_stored and H == W)
+    if sv["interp"] and R:
+        # register encoders are the hub's dinov2_vit*14_reg (anti-aliased, size-based resampling: models/dino.py::_pos_patch); the
+        # adjoint of that filter is not built -- train them at the stored grid (518 x 518 for the hub weights)
+        raise NotImplementedError("training step: register-token encoders train at their stored position grid only (the adjoint of the "
+                                  "anti-aliased position resampling is not on the HIP backward)")
     pos_patch = hip.pos_embed_interp(pos[1:].contiguous(), Mg, gh, gw, 0.1) if sv["interp"] else pos[1:].contiguous()
-    prefix = torch.empty((1, E), dtype=torch.float32, device=dev)
-    prefix.copy_(pos[:1])
-    hip.axpby_cols(enc.cls_token.detach().reshape(1, E), prefix)
+    prefix = torch.zeros((1 + R, E), dtype=torch.float32, device=dev)
+    prefix[:1].copy_(pos[:1])
+    hip.axpby_cols(enc.cls_token.detach().reshape(1, E), prefix[:1])
+    if R:
+        prefix[1:].copy_(enc.register_tokens.detach()[0])
     wsum = torch.zeros((E, PATCH * 16), dtype=torch.float32, device=dev)            # three identical input channels: one summed kernel
     w = enc.patch_embed.proj.weight.detach()
     for c in range(3):
@@ -284,7 +291,8 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
     n = B * D
     gh, gw = H // PATCH, W // PATCH
     Np = gh * gw
-    N = 1 + Np
+    R = sv["R"]
+    N = 1 + R + Np
     M = n * N
     dx = torch.zeros((M, E), dtype=torch.float32, device=dev)
     G.ln_bwd(sv["xL"], N * E, enc.norm, demb, E, None, 0, dx, N * E, n, E, 1e-6)                         # CLS rows only
@@ -316,7 +324,12 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
     dcls = torch.zeros(E, dtype=torch.float32, device=dev)
     hip._check(hip.load().mst_colsum(hip.ptr(dx), N * E, None, 0, n, E, hip.ptr(dcls), hip.stream_of(dx)), "mst_colsum")
     G.put(enc.cls_token, dcls.clone())
-    dpatch = dx.view(n, N, E)[:, 1:].contiguous().view(n * Np, E)
+    if R:                                                # d register_tokens[r] = sum over slices of row 1 + r
+        dreg = torch.zeros((R, E), dtype=torch.float32, device=dev)
+        for r in range(R):
+            hip._check(hip.load().mst_colsum(hip.ptr(dx) + (1 + r) * E * 4, N * E, None, 0, n, E, hip.ptr(dreg) + r * E * 4, hip.stream_of(dx)), "mst_colsum")
+        G.put(enc.register_tokens, dreg.view(1, R, E))
+    dpatch = dx.view(n, N, E)[:, 1 + R:].contiguous().view(n * Np, E)
     dposp = torch.zeros(Np * E, dtype=torch.float32, device=dev)
     hip.colsum(dpatch.view(n, Np * E), dposp)
     dpos = torch.zeros_like(enc.pos_embed)
