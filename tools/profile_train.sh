@@ -14,3 +14,4 @@ for r in rows[:14]:
     print(f'{r["Name"][:64]:64s} calls {r["Calls"]:>6s} avg_us {float(r["AverageNs"])/1e3:8.1f} total_ms {float(r["TotalDurationNs"])/1e6:8.1f} {r["Percentage"]}%')
 PY
 tail -2 $OUT/stdout.log
+find $OUT -type f \( -name "*.db" -o -name "*_kernel_trace.csv" -o -name "*agent_info.csv" \) -delete 2>/dev/null || true
