@@ -115,6 +115,8 @@ def self_launch(args) -> int:
         print(f"[bench] --gpus {args.gpus} requested but only {have} device(s) are visible", file=sys.stderr)
         return 3
     env = dict(os.environ)
+    # dmabuf is the only IPC mode the host driver of this pool supports: without it RCCL's buffer exchange between the ranks fails with
+    # "hipIpcGetMemHandle: invalid argument" (the image exports it already; kept explicit for launches from a clean environment)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     port = env.get("MASTER_PORT") or str(29400 + os.getpid() % 500)

@@ -135,6 +135,12 @@ int mst_patch_embed(const void* vol, int in_dtype, int n, int H, int W, const vo
  * mst_avgpool_nhwc: x [n, HW, C] -> y [n, C], the adaptive average pool to 1x1. */
 int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* col,
                     mst_stream_t stream);
+/* mst_conv_gemm: the same convolution (+ folded BatchNorm bias, ReLU / residual epilogues of mst_gemm) as an IMPLICIT GEMM: the A operand
+ * is gathered from x [n,H,W,Cin] on the fly, no [rows, kh*kw*Cin] matrix is materialised (9x the activation for a 3x3 layer).  Cin % 16
+ * == 0 (every layer behind the stem); Wg [Cout, Kpad] and the (ky, kx, c) order as above; out [n*Ho*Wo, Cout] fp32 (read and written
+ * by MST_EPI_RESIDUAL); epilogue MST_EPI_BIAS / MST_EPI_BIAS_RELU / MST_EPI_RESIDUAL. */
+int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, const float* bias,
+                  float* out, int Cout, int Kpad, int epilogue, const float* gamma, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);
 int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream);
 /* Training step of the backbone (BASELINE configs[3]; what torch.autograd + nn.BatchNorm2d(train) do for the reference):

@@ -17,13 +17,19 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, LDP = 17;
 
-template <int EPI>
+// CONV: implicit-GEMM convolution.  A is not a matrix but the NHWC activation x [n, H, W, Cin]: row m = output pixel (img, oy, ox),
+// column k = (ky, kx, c) with c fastest -- what mst_im2col_nhwc would have written, gathered on the fly (a 16-wide k-step stays inside
+// one filter tap because Cin % 16 == 0, so the tap is a scalar per k-step and a thread's float4 is four consecutive channels of
+// one input pixel, or zero outside the image).  No [rows, kh*kw*Cin] matrix exists in memory (9x the activation for a 3x3 layer).
+struct ConvGeom { int H, W, C, kh, kw, stride, pad, Ho, Wo; };
+
+template <int EPI, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A, int64_t lda,
                                                      const float* __restrict__ W, int64_t ldw,
                                                      const float* __restrict__ bias, float* C,
                                                      int64_t ldc, int M, int N, int K,
                                                      const float* __restrict__ gamma, float col_scale,
-                                                     int scale_cols, int tiles_n, int nwg) {
+                                                     int scale_cols, int tiles_n, int nwg, ConvGeom cg = ConvGeom{}) {
     __shared__ float As[BM * LDP];
     __shared__ float Ws[BN * LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,10 +40,38 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A
     // staging map: 2 float4 per operand per thread
     const int srow0 = tid >> 2, skq = (tid & 3) * 4;  // rows srow0 and srow0 + 64
     float4 ra[2], rw[2];
+    int c_img[2] = {0, 0}, c_y[2] = {0, 0}, c_x[2] = {0, 0};       // CONV: this thread's two output pixels
+    if constexpr (CONV) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = m0 + srow0 + u * 64;
+            const int hw = cg.Ho * cg.Wo;
+            const int mm = m < M ? m : M - 1;
+            c_img[u] = mm / hw;
+            const int rem = mm - c_img[u] * hw;
+            c_y[u] = (rem / cg.Wo) * cg.stride - cg.pad;
+            c_x[u] = (rem % cg.Wo) * cg.stride - cg.pad;
+        }
+    }
     auto gload = [&](int k0) {
+        int ky = 0, kx = 0, c0 = 0;
+        bool tap_ok = true;
+        if constexpr (CONV) {
+            const int tap = k0 / cg.C;                   // scalar: the whole k-step lies in one filter tap
+            c0 = k0 - tap * cg.C + skq;
+            ky = tap / cg.kw;
+            kx = tap - ky * cg.kw;
+            tap_ok = tap < cg.kh * cg.kw;                // K is padded to a multiple of 16 with zero weights
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = srow0 + u * 64;
+            if constexpr (CONV) {
+                const int iy = c_y[u] + ky, ix = c_x[u] + kx;
+                const bool ok = tap_ok && m0 + row < M && iy >= 0 && iy < cg.H && ix >= 0 && ix < cg.W;
+                ra[u] = ok ? *reinterpret_cast<const float4*>(A + (((int64_t)c_img[u] * cg.H + iy) * cg.W + ix) * cg.C + c0)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else
             ra[u] = (m0 + row < M) ? *reinterpret_cast<const float4*>(A + (int64_t)(m0 + row) * lda + k0 + skq)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
             rw[u] = (n0 + row < N) ? *reinterpret_cast<const float4*>(W + (int64_t)(n0 + row) * ldw + k0 + skq)
@@ -134,7 +168,35 @@ int launch_t(const float* A, int64_t lda, const float* W, int64_t ldw, const flo
     return mst_check_launch("gemm32");
 }
 
+template <int EPI>
+int launch_conv_t(const float* x, const ConvGeom& cg, int n, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int N,
+                  int K, const float* gamma, hipStream_t s) {
+    const int64_t M = (int64_t)n * cg.Ho * cg.Wo;
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    gemm32_kernel<EPI, true><<<dim3(nwg), dim3(256), 0, s>>>(x, 0, W, ldw, bias, C, ldc, (int)M, N, K, gamma, 1.f, 0, tiles_n, nwg, cg);
+    return mst_check_launch("conv_gemm32");
+}
+
 }  // namespace
+
+// out[(img, oy, ox)][co] = epi(sum_{ky,kx,c} x[img][oy*stride-pad+ky][ox*stride-pad+kx][c] * Wg[co][(ky,kx,c)] + bias[co]): the
+// convolution as an implicit GEMM (no im2col matrix).  Wg [Cout, Kpad] as for mst_im2col_nhwc + mst_gemm; Cin % 16 == 0.
+int launch_conv_gemm32(const float* x, int n, int H, int W_, int Cin, int kh, int kw, int stride, int pad, const float* Wg, int64_t ldw,
+                       const float* bias, float* out, int64_t ldc, int Cout, int Kpad, int epi, const float* gamma, hipStream_t s) {
+    MST_CHECK_ARG(x && Wg && out && n > 0 && H > 0 && W_ > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv_gemm: bad arguments");
+    MST_CHECK_ARG(Cin % 16 == 0, "conv_gemm: Cin=%d must be a multiple of 16 (use mst_im2col_nhwc + mst_gemm otherwise)", Cin);
+    MST_CHECK_ARG(Kpad >= kh * kw * Cin && Kpad % BK == 0 && ldw % 4 == 0 && ldw >= Kpad, "conv_gemm: Kpad=%d / ldw", Kpad);
+    ConvGeom cg{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1};
+    MST_CHECK_ARG(cg.Ho > 0 && cg.Wo > 0 && (int64_t)n * cg.Ho * cg.Wo < (1ll << 31) - BM, "conv_gemm: output %d x %d x %d", n, cg.Ho, cg.Wo);
+    switch (epi) {
+        case MST_EPI_BIAS: return launch_conv_t<MST_EPI_BIAS>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
+        case MST_EPI_BIAS_RELU: return launch_conv_t<MST_EPI_BIAS_RELU>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
+        case MST_EPI_RESIDUAL: return launch_conv_t<MST_EPI_RESIDUAL>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
+    }
+    mst_set_error("conv_gemm: epilogue %d unsupported (bias, bias + ReLU, residual)", epi);
+    return MST_EINVAL;
+}
 
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,

@@ -225,6 +225,10 @@ int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, 
     MST_CHECK_ARG(x && col && n > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "im2col_nhwc: bad arguments");
     return launch_im2col_nhwc(x, n, H, W, C, kh, kw, stride, pad, Kpad, col, (hipStream_t)stream);
 }
+int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, const float* bias,
+                  float* out, int Cout, int Kpad, int epilogue, const float* gamma, mst_stream_t stream) {
+    return launch_conv_gemm32(x, n, H, W, Cin, kh, kw, stride, pad, Wg, Kpad, bias, out, Cout, Cout, Kpad, epilogue, gamma, (hipStream_t)stream);
+}
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");
     return launch_maxpool_nhwc(x, n, H, W, C, y, (hipStream_t)stream);

@@ -166,6 +166,8 @@ int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+int launch_conv_gemm32(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, int64_t ldw,
+                       const float* bias, float* out, int64_t ldc, int Cout, int Kpad, int epi, const float* gamma, hipStream_t s);
 bool gemm32_small_applicable(int64_t M, int N, int K);
 int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc,
                         int64_t M, int N, int K, int epi, const float* gamma, float col_scale, int scale_cols, hipStream_t s);

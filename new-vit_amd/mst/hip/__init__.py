@@ -82,6 +82,7 @@ SIGNATURES = {
     "mst_im2col14": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp_bwd": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
     "mst_im2col_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_batchnorm_train": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -371,7 +372,7 @@ def pack_block_seq(proj_w, proj_b, ls1, fc1_w, fc1_b, fc2_w, fc2_b, ln_w, ln_b, 
         wp = wp * ls1.float()[:, None]
         pbf = pbf * ls1.float()
     w1 = fc1_w.float() * ln_w.float()[None, :]
-    b1f = fc1_b.float() + fc1_w.float() @ ln_b.float()
+    b1f = fc1_b.float() + (fc1_w.float() * ln_b.float()[None, :]).sum(dim=1)      # (weight preparation without a vendor BLAS call)
     w2 = fc2_w.float()
     b2f = fc2_b.float().clone()
     if ls2 is not None:
@@ -432,7 +433,7 @@ def pack_mlp(fc1_w, fc1_b, fc2_w, fc2_b, ln_w, ln_b, ls2, dtype: torch.dtype):
     Returns (wpack [48,24576] dtype, b1f [1568] fp32, b2f [384] fp32)."""
     dev = fc1_w.device
     w1f = fc1_w.float() * ln_w.float()[None, :]
-    b1f = fc1_b.float() + fc1_w.float() @ ln_b.float()
+    b1f = fc1_b.float() + (fc1_w.float() * ln_b.float()[None, :]).sum(dim=1)      # (weight preparation without a vendor BLAS call)
     b2f = fc2_b.float().clone()
     if ls2 is not None:                                   # LayerScale folded into fc2 (layer_scale.py:26-27)
         fc2_w = fc2_w.float() * ls2.float()[:, None]
@@ -629,6 +630,21 @@ def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, kpad: 
     col = torch.empty((n * Ho * Wo, kpad), dtype=torch.float32, device=x.device)
     _check(load().mst_im2col_nhwc(ptr(x), n, H, W, Cc, kh, kw, stride, pad, kpad, ptr(col), stream_of(x)), "mst_im2col_nhwc")
     return col
+
+
+def conv_gemm(x: torch.Tensor, wg: torch.Tensor, bias: Optional[torch.Tensor], kh: int, kw: int, stride: int, pad: int, *,
+              epilogue: int = EPI_BIAS, out: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Convolution of x [n,H,W,Cin] (NHWC fp32, Cin % 16 == 0) with the GEMM-form weight wg [Cout, Kpad] ((ky, kx, c) order) as an
+    implicit GEMM (mst_conv_gemm: no im2col matrix) -> [n*Ho*Wo, Cout].  out: the residual operand of EPI_RESIDUAL (updated in place)."""
+    _dev(x, "conv_gemm")
+    n, H, W, Cin = x.shape
+    Cout, kpad = wg.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+    _check(load().mst_conv_gemm(ptr(x), n, H, W, Cin, kh, kw, stride, pad, ptr(wg), ptr(bias), ptr(out), Cout, kpad, epilogue, ptr(gamma),
+                                stream_of(x)), "mst_conv_gemm")
+    return out
 
 
 def maxpool_nhwc(x: torch.Tensor) -> torch.Tensor:

@@ -432,7 +432,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
                     be1 = b.norm1.bias.detach().to(dev, torch.float32)
                     wq = b.attn.qkv.weight.detach().to(dev, torch.float32)
                     L.qkv_wf = hip.ptr(cmp(wq * g1[None, :]))
-                    L.qkv_bf = hip.ptr(f32(b.attn.qkv.bias.detach().to(dev, torch.float32) + wq @ be1))
+                    L.qkv_bf = hip.ptr(f32(b.attn.qkv.bias.detach().to(dev, torch.float32) + (wq * be1[None, :]).sum(dim=1)))   # (no vendor BLAS: an elementwise product + row sums, once per weight version)
                     ls = b.ls2.gamma.detach().to(dev) if hasattr(b, "ls2") else None
                     wpack, b1p, b2p = hip.pack_mlp(b.mlp.fc1.weight.detach().to(dev), b.mlp.fc1.bias.detach().to(dev),
                                                    b.mlp.fc2.weight.detach().to(dev), b.mlp.fc2.bias.detach().to(dev),

@@ -6,7 +6,9 @@ Same constructors, ``forward`` signatures, getters and ``state_dict`` keys as th
 Transformer with 16 heads over 512-wide slice embeddings, ``cls_token`` and ``linear``: resnet.py:146-166).  The modules below are
 parameter containers; the arithmetic runs in HIP kernels through the C ABI:
 
-  backbone   NHWC fp32 activations; every convolution = ``mst_im2col_nhwc`` + the exact-fp32 MFMA GEMM (``mst_gemm``) with eval-mode
+  backbone   NHWC fp32 activations; every convolution behind the stem = ``mst_conv_gemm`` (implicit GEMM: the exact-fp32 MFMA GEMM
+             gathering its A operand from the activation, no im2col matrix); the stem (one input channel after the gray fold) =
+             ``mst_im2col_nhwc`` + ``mst_gemm``; eval-mode
              BatchNorm folded into weight and bias and ReLU / the residual add in the GEMM epilogue; ``mst_maxpool_nhwc``,
              ``mst_avgpool_nhwc``.  Gray -> RGB (``x.repeat(1, 3, ...)``, resnet.py:176) is folded into conv1 (the three input
              channels are identical, so their kernels are summed).
@@ -29,6 +31,7 @@ is initialised like torchvision's and a warning says so -- a checkpoint's ``stat
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import List, Optional
 
@@ -120,6 +123,17 @@ class _TVResNet(_P):
             setattr(self, f"layer{li + 1}", nn.ModuleList(blocks))
         self.out_features = cin
         self.fc = nn.Identity() if fc_out is None else _Linear(cin, fc_out)
+
+
+def _conv(x: torch.Tensor, w: torch.Tensor, b, k: int, stride: int, pad: int, kpad: int, epilogue: int, out=None) -> torch.Tensor:
+    """One convolution of the backbone on an NHWC activation -> [n*Ho*Wo, Cout]: the implicit GEMM (mst_conv_gemm) when the input
+    channels allow it (Cin % 16 == 0: every layer behind the stem) and there are more than 1,024 output pixels, else im2col + GEMM.  MST_CONV_IM2COL=1 forces the latter (A/B)."""
+    n, H, W, cin = x.shape
+    rows = n * ((H + 2 * pad - k) // stride + 1) * ((W + 2 * pad - k) // stride + 1)
+    # up to 1,024 output pixels mst_gemm has its 32 x 32-tile kernel (k_gemm32s.hip), which fills the chip where 128 x 128 tiles cannot
+    if cin % 16 == 0 and rows > 1024 and os.environ.get("MST_CONV_IM2COL", "0") != "1":
+        return hip.conv_gemm(x, w, b, k, k, stride, pad, epilogue=epilogue, out=out)
+    return hip.gemm(hip.im2col_nhwc(x, k, k, stride, pad, kpad), w, b, epilogue=epilogue, out=out)
 
 
 def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev):
@@ -222,27 +236,27 @@ class ResNet(BasicClassifier):
                 Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
                 w1, b1, k1 = e["c1"]
                 if "c3" in e:                            # bottleneck: 1x1 -> 3x3 (stride) -> 1x1, the residual joins after the third
-                    h0 = hip.gemm(hip.im2col_nhwc(y, 1, 1, 1, 0, k1), w1, b1, epilogue=hip.EPI_BIAS_RELU).view(n, H, W, w1.shape[0])
+                    h0 = _conv(x=y, w=w1, b=b1, k=1, stride=1, pad=0, kpad=k1, epilogue=hip.EPI_BIAS_RELU).view(n, H, W, w1.shape[0])
                     w2, b2, k2 = e["c2"]
-                    h1 = hip.gemm(hip.im2col_nhwc(h0, 3, 3, s, 1, k2), w2, b2, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w2.shape[0])
+                    h1 = _conv(x=h0, w=w2, b=b2, k=3, stride=s, pad=1, kpad=k2, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w2.shape[0])
                     if "ds" in e:
                         wd, bd, kd = e["ds"]
-                        idt = hip.gemm(hip.im2col_nhwc(y, 1, 1, s, 0, kd), wd, bd, epilogue=hip.EPI_BIAS)
+                        idt = _conv(x=y, w=wd, b=bd, k=1, stride=s, pad=0, kpad=kd, epilogue=hip.EPI_BIAS)
                     else:
                         idt = y.reshape(n * H * W, Cin).clone()
                     w3, b3, k3 = e["c3"]
-                    hip.gemm(hip.im2col_nhwc(h1, 1, 1, 1, 0, k3), w3, b3, epilogue=hip.EPI_RESIDUAL, out=idt)
+                    _conv(x=h1, w=w3, b=b3, k=1, stride=1, pad=0, kpad=k3, epilogue=hip.EPI_RESIDUAL, out=idt)
                     hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))
                     y = idt.view(n, Ho, Wo, w3.shape[0])
                     continue
-                h1 = hip.gemm(hip.im2col_nhwc(y, 3, 3, s, 1, k1), w1, b1, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w1.shape[0])
+                h1 = _conv(x=y, w=w1, b=b1, k=3, stride=s, pad=1, kpad=k1, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w1.shape[0])
                 if "ds" in e:
                     wd, bd, kd = e["ds"]
-                    idt = hip.gemm(hip.im2col_nhwc(y, 1, 1, s, 0, kd), wd, bd, epilogue=hip.EPI_BIAS)
+                    idt = _conv(x=y, w=wd, b=bd, k=1, stride=s, pad=0, kpad=kd, epilogue=hip.EPI_BIAS)
                 else:
                     idt = y.reshape(n * H * W, Cin).clone()
                 w2, b2, k2 = e["c2"]
-                hip.gemm(hip.im2col_nhwc(h1, 3, 3, 1, 1, k2), w2, b2, epilogue=hip.EPI_RESIDUAL, out=idt)      # identity + bn2(conv2(.))
+                _conv(x=h1, w=w2, b=b2, k=3, stride=1, pad=1, kpad=k2, epilogue=hip.EPI_RESIDUAL, out=idt)      # identity + bn2(conv2(.))
                 hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))          # ReLU in place
                 y = idt.view(n, Ho, Wo, w2.shape[0])
             outs.append(hip.avgpool_nhwc(y))

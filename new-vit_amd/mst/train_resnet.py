@@ -4,7 +4,8 @@ The reference trains these through torch.autograd over torchvision's modules (ms
 mst/models/resnet.py:172-193).  Here, as for DinoV2ClassifierSlice (mst/train.py), the logits carry ONE autograd node whose
 forward runs the model op by op through the C ABI and whose backward produces every parameter gradient with HIP kernels:
 
-  convolution      z = im2col(x) . Wg^T             (mst_im2col_nhwc + mst_gemm, exact fp32 MFMA; Wg = weight in (ky, kx, c) order)
+  convolution      z = im2col(x) . Wg^T             (mst_conv_gemm: implicit GEMM, exact fp32 MFMA; the stem: mst_im2col_nhwc + mst_gemm;
+                                                     Wg = weight in (ky, kx, c) order)
      backward      dWg = dz^T . im2col(x) (split over images, partial sums reduced by mst_colsum), dx = col2im(dz . Wg)
   BatchNorm2d      batch statistics + running-stat update (mst_batchnorm_train), residual add and ReLU in the same pass
      backward      mst_batchnorm_bwd (ReLU mask first: mst_act_bwd on the saved output)
@@ -24,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from .models.resnet import _conv
 from .train import _Grads, fusion_bwd, fusion_fwd
 
 
@@ -46,7 +48,7 @@ def _conv_bn_fwd(x: torch.Tensor, conv, bn, k: int, stride: int, pad: int, sum_i
     n, H, W, _ = x.shape
     wg = _gemm_weight(conv, sum_in)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    z = hip.gemm(hip.im2col_nhwc(x, k, k, stride, pad, wg.shape[1]), wg, None, epilogue=hip.EPI_BIAS)
+    z = _conv(x, wg, None, k, stride, pad, wg.shape[1], hip.EPI_BIAS)        # implicit GEMM behind the stem
     y, mean, rstd = hip.batchnorm_train(z, bn, residual, relu)
     bn.num_batches_tracked += 1
     rec = {"x": x, "z": z, "y": y if relu else None, "mean": mean, "rstd": rstd, "wg": wg, "k": k, "stride": stride, "pad": pad,

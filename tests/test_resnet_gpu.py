@@ -273,6 +273,52 @@ def test_conv_batchnorm_unit_forward_and_backward_match_torch(cin, cout, k, stri
         assert rel_l2(dyh.view(n, Ho, Wo, cout).permute(0, 3, 1, 2).cpu(), dy.double() * (y.detach() > 0)) < 1e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw,kextra", [
+    (5, 64, 64, 3, 1, 1, (16, 15), 0), (3, 64, 128, 3, 2, 1, (41, 37), 0), (5, 128, 256, 1, 2, 0, (35, 27), 0), (2, 16, 96, 3, 1, 1, (7, 5), 16),
+    (1, 256, 64, 1, 1, 0, (3, 3), 0), (2, 80, 200, 3, 2, 1, (53, 49), 0), (7, 512, 512, 3, 1, 1, (2, 2), 0), (9, 16, 40, 3, 1, 1, (13, 11), 32)])
+@pytest.mark.parametrize("epi", ["bias", "relu", "residual"])
+def test_implicit_gemm_convolution_equals_im2col_gemm_and_torch(n, cin, cout, k, stride, pad, hw, kextra, epi):
+    """mst_conv_gemm gathers the A operand the im2col matrix would hold, in the same k order and tiles: bit-identical to
+    mst_im2col_nhwc + mst_gemm (where that runs the same 128 x 128-tile kernel: more than 1,024 rows) for every epilogue, ragged row
+    counts, padding rows/columns, a zero-padded K; and equal to torch's fp64 conv2d to fp32 accuracy."""
+    import torch.nn.functional as F
+    from mst import hip
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + k)
+    x = torch.randn(n, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    K = k * k * cin
+    kpad = K + kextra
+    wg = torch.zeros(cout, kpad)
+    wg[:, :K] = w.permute(0, 2, 3, 1).reshape(cout, K)
+    Ho, Wo = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
+    res = torch.randn(n * Ho * Wo, cout, generator=g)
+    e = {"bias": hip.EPI_BIAS, "relu": hip.EPI_BIAS_RELU, "residual": hip.EPI_RESIDUAL}[epi]
+    xh, wh, bh = x.permute(0, 2, 3, 1).contiguous().cuda(), wg.cuda(), b.cuda()
+    o1 = res.cuda().clone() if epi == "residual" else None
+    o2 = res.cuda().clone() if epi == "residual" else None
+    got = hip.conv_gemm(xh, wh, bh, k, k, stride, pad, epilogue=e, out=o1)
+    via = hip.gemm(hip.im2col_nhwc(xh, k, k, stride, pad, kpad), wh, bh, epilogue=e, out=o2)
+    assert got.shape == (n * Ho * Wo, cout)
+    if n * Ho * Wo > 1024:                              # same kernel, same k order, same tiles
+        assert torch.equal(got, via)
+    else:                                               # mst_gemm takes its 32 x 32-tile kernel here: another summation order
+        assert rel_l2(got.cpu(), via.cpu()) < 1e-6
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(-1, cout)
+    want = F.relu(want) if epi == "relu" else want + res.double() if epi == "residual" else want
+    assert rel_l2(got.cpu(), want) < 1e-5
+
+
+def test_implicit_gemm_convolution_rejects_what_it_cannot_gather():
+    from mst import hip
+    x = torch.zeros(1, 4, 4, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        hip.conv_gemm(x, torch.zeros(8, 32, device="cuda"), None, 3, 3, 1, 1)
+    x = torch.zeros(1, 4, 4, 16, device="cuda")
+    with pytest.raises(RuntimeError, match="Kpad"):
+        hip.conv_gemm(x, torch.zeros(8, 128, device="cuda"), None, 3, 3, 1, 1)
+
+
 def test_pool_backward_kernels_match_torch():
     import torch.nn.functional as F
     from mst import hip
