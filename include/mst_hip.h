@@ -39,7 +39,8 @@ enum mst_epilogue {
     MST_EPI_BIAS = 0,      /* C = A W^T + b                               (any linear)            */
     MST_EPI_BIAS_GELU = 1, /* C = gelu_erf(A W^T + b)                     mlp.py:34-36            */
     MST_EPI_BIAS_RELU = 2, /* C = relu(A W^T + b)                         transformer_blocks.py:586 */
-    MST_EPI_RESIDUAL = 3   /* C(f32) += gamma * (A W^T + b)               block.py:90-94,112-113  */
+    MST_EPI_RESIDUAL = 3,  /* C(f32) += gamma * (A W^T + b)               block.py:90-94,112-113  */
+    MST_EPI_RESIDUAL_RELU = 4 /* C(f32) = relu(C + gamma * (A W^T + b))    resnet BasicBlock / Bottleneck exit; fp32 operands only */
 };
 
 enum mst_fusion_type { MST_FUSION_TRANSFORMER = 0, MST_FUSION_LINEAR = 1, MST_FUSION_AVERAGE = 2 };
@@ -138,7 +139,7 @@ int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, 
 /* mst_conv_gemm: the same convolution (+ folded BatchNorm bias, ReLU / residual epilogues of mst_gemm) as an IMPLICIT GEMM: the A operand
  * is gathered from x [n,H,W,Cin] on the fly, no [rows, kh*kw*Cin] matrix is materialised (9x the activation for a 3x3 layer).  Cin % 16
  * == 0 (every layer behind the stem); Wg [Cout, Kpad] and the (ky, kx, c) order as above; out [n*Ho*Wo, Cout] fp32 (read and written
- * by MST_EPI_RESIDUAL); epilogue MST_EPI_BIAS / MST_EPI_BIAS_RELU / MST_EPI_RESIDUAL. */
+ * by MST_EPI_RESIDUAL / _RESIDUAL_RELU); epilogue MST_EPI_BIAS / MST_EPI_BIAS_RELU / MST_EPI_RESIDUAL / MST_EPI_RESIDUAL_RELU. */
 int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, const float* bias,
                   float* out, int Cout, int Kpad, int epilogue, const float* gamma, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);

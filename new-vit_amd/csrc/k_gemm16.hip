@@ -205,6 +205,7 @@ int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw
     MST_CHECK_ARG(M < (1ll << 31) - BM, "gemm16: M too large");
     MST_CHECK_ARG(cdt == MST_F32 || cdt == dt, "gemm16: C dtype must be f32 or the operand dtype");
     MST_CHECK_ARG(epi != MST_EPI_RESIDUAL || cdt == MST_F32, "gemm16: residual epilogue needs f32 C");
+    MST_CHECK_ARG(epi != MST_EPI_RESIDUAL_RELU, "gemm16: the residual + ReLU epilogue exists for f32 operands only");
     if (M <= 0) return MST_OK;
     static const bool big_ok = !(getenv("MST_GEMM_BIG") && atoi(getenv("MST_GEMM_BIG")) == 0);
     // measured on MI355X (tools/bench_gemm.py): the read-modify-write epilogue of the residual GEMMs is

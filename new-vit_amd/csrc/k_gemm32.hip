@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A
 
     // epilogue: D[row = n_local = (r&3)+8*(r>>2)+4*(lane>>5)][col = m_local = lane&31]
     const bool vec_ok = (ldc % 4 == 0);
+    constexpr bool RES = (EPI == MST_EPI_RESIDUAL || EPI == MST_EPI_RESIDUAL_RELU);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -137,22 +138,23 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A
                         if (n + e < scale_cols) t *= col_scale;
                         if (EPI == MST_EPI_BIAS_GELU) t = gelu_erf(t);
                         if (EPI == MST_EPI_BIAS_RELU) t = fmaxf(t, 0.f);
-                        if (EPI == MST_EPI_RESIDUAL && gamma) t *= gamma[n + e];
+                        if (RES && gamma) t *= gamma[n + e];
                     }
                     v[e] = t;
                 }
                 float* cp = C + (int64_t)m * ldc + n;
                 if (vec_ok && n + 3 < N) {
                     float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (EPI == MST_EPI_RESIDUAL) {
+                    if (RES) {
                         const float4 xv = *reinterpret_cast<const float4*>(cp);
                         o.x += xv.x; o.y += xv.y; o.z += xv.z; o.w += xv.w;
+                        if (EPI == MST_EPI_RESIDUAL_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
                     }
                     *reinterpret_cast<float4*>(cp) = o;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < N) cp[e] = (EPI == MST_EPI_RESIDUAL) ? cp[e] + v[e] : v[e];
+                        if (n + e < N) cp[e] = (EPI == MST_EPI_RESIDUAL_RELU) ? fmaxf(cp[e] + v[e], 0.f) : RES ? cp[e] + v[e] : v[e];
                 }
             }
         }
@@ -193,8 +195,9 @@ int launch_conv_gemm32(const float* x, int n, int H, int W_, int Cin, int kh, in
         case MST_EPI_BIAS: return launch_conv_t<MST_EPI_BIAS>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
         case MST_EPI_BIAS_RELU: return launch_conv_t<MST_EPI_BIAS_RELU>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
         case MST_EPI_RESIDUAL: return launch_conv_t<MST_EPI_RESIDUAL>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
+        case MST_EPI_RESIDUAL_RELU: return launch_conv_t<MST_EPI_RESIDUAL_RELU>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
     }
-    mst_set_error("conv_gemm: epilogue %d unsupported (bias, bias + ReLU, residual)", epi);
+    mst_set_error("conv_gemm: epilogue %d unsupported (bias, bias + ReLU, residual, residual + ReLU)", epi);
     return MST_EINVAL;
 }
 
@@ -214,6 +217,7 @@ int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, cons
         case MST_EPI_BIAS_GELU: return launch_t<MST_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
         case MST_EPI_BIAS_RELU: return launch_t<MST_EPI_BIAS_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
         case MST_EPI_RESIDUAL: return launch_t<MST_EPI_RESIDUAL>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+        case MST_EPI_RESIDUAL_RELU: return launch_t<MST_EPI_RESIDUAL_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
     }
     mst_set_error("gemm32: bad epilogue %d", epi);
     return MST_EINVAL;

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void gemm32s_kernel(const float* __restrict__ A
     if (m >= M) return;
     // D[row = n_local = (r&3) + 8 (r>>2) + 4 hi][col = m_local = lane & 31]
     const bool vec_ok = (ldc % 4 == 0);
+    constexpr bool RES = (EPI == MST_EPI_RESIDUAL || EPI == MST_EPI_RESIDUAL_RELU);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int nn = n0 + 8 * q + 4 * hi;
@@ -51,22 +52,23 @@ __global__ __launch_bounds__(64) void gemm32s_kernel(const float* __restrict__ A
                 if (nn + e < scale_cols) t *= col_scale;
                 if (EPI == MST_EPI_BIAS_GELU) t = gelu_erf(t);
                 if (EPI == MST_EPI_BIAS_RELU) t = fmaxf(t, 0.f);
-                if (EPI == MST_EPI_RESIDUAL && gamma) t *= gamma[nn + e];
+                if (RES && gamma) t *= gamma[nn + e];
             }
             v[e] = t;
         }
         float* cp = C + (int64_t)m * ldc + nn;
         if (vec_ok && nn + 3 < N) {
             float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            if (EPI == MST_EPI_RESIDUAL) {
+            if (RES) {
                 const float4 xv = *reinterpret_cast<const float4*>(cp);
                 o.x += xv.x; o.y += xv.y; o.z += xv.z; o.w += xv.w;
+                if (EPI == MST_EPI_RESIDUAL_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             }
             *reinterpret_cast<float4*>(cp) = o;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (nn + e < N) cp[e] = (EPI == MST_EPI_RESIDUAL) ? cp[e] + v[e] : v[e];
+                if (nn + e < N) cp[e] = (EPI == MST_EPI_RESIDUAL_RELU) ? fmaxf(cp[e] + v[e], 0.f) : RES ? cp[e] + v[e] : v[e];
         }
     }
 }
@@ -90,6 +92,7 @@ int launch_gemm32_small(const float* A, int64_t lda, const float* W, int64_t ldw
         case MST_EPI_BIAS_GELU: return launch_t<MST_EPI_BIAS_GELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
         case MST_EPI_BIAS_RELU: return launch_t<MST_EPI_BIAS_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
         case MST_EPI_RESIDUAL: return launch_t<MST_EPI_RESIDUAL>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
+        case MST_EPI_RESIDUAL_RELU: return launch_t<MST_EPI_RESIDUAL_RELU>(A, lda, W, ldw, bias, C, ldc, M, N, K, gamma, col_scale, scale_cols, s);
     }
     mst_set_error("gemm32s: bad epilogue %d", epi);
     return MST_EINVAL;

@@ -2,8 +2,8 @@
 // (v_mfma_f32_32x32x2_f32): the first correct version -- gradients are checked against autograd of the CPU oracle at the
 // fp32 bar.  What the reference gets from torch.autograd (base_model.py:148-181 `_step`; main_train.py:110-126) is spelled out
 // here op by op:
-//   gemm_ex        C[b] = alpha * A[b] . B[b] (+ beta * C[b]), every operand with explicit element strides and a two-level batch:
-//                  one kernel covers dX = dY.W, dW = dY^T.X, and the four products of the attention backward on the packed
+//   gemm_ex        (k_gemm_ex.hip) C[b] = alpha * A[b] . B[b] (+ beta * C[b]), every operand with explicit element strides and a two-level
+//                  batch: one entry covers dX = dY.W, dW = dY^T.X, and the four products of the attention backward on the packed
 //                  q|k|v layout of the forward (attention.py:56-66)
 //   softmax_rows / softmax_rows_bwd     P = softmax(S + key-padding mask),  dS = P o (dP - rowsum(dP o P))
 //   layernorm_bwd  dx (+ residual gradient), d gamma, d beta   (nn.LayerNorm; block.py:63,75; transformer_blocks.py:499)
@@ -14,57 +14,6 @@
 #include "mst_common.h"
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------------------------
-// generic strided, batched GEMM.  64 x 64 tile per 256-thread workgroup, four waves 2 x 2, K-step 16.
-struct GemmExArgs {
-    const float* A; const float* B; float* C;
-    int M, N, K, nb2;
-    int64_t sam, sak, sbk, sbn, scm, scn;          // element strides of A[m][k], B[k][n], C[m][n]
-    int64_t sa1, sa2, sb1, sb2, sc1, sc2;          // batch strides: batch index = b1 * nb2 + b2
-    float alpha, beta;
-};
-
-__global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
-    __shared__ float As[16][65], Bs[16][65];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
-    const float* A = g.A + b1 * g.sa1 + b2 * g.sa2;
-    const float* B = g.B + b1 * g.sb1 + b2 * g.sb2;
-    float* C = g.C + b1 * g.sc1 + b2 * g.sc2;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const bool a_kmajor = g.sak == 1, b_nmajor = g.sbn == 1;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e;
-            const int am = a_kmajor ? idx >> 4 : idx & 63, ak = a_kmajor ? idx & 15 : idx >> 6;
-            const int bn = b_nmajor ? idx & 63 : idx >> 4, bk = b_nmajor ? idx >> 6 : idx & 15;
-            As[ak][am] = (m0 + am < g.M && k0 + ak < g.K) ? A[(int64_t)(m0 + am) * g.sam + (int64_t)(k0 + ak) * g.sak] : 0.f;
-            Bs[bk][bn] = (n0 + bn < g.N && k0 + bk < g.K) ? B[(int64_t)(k0 + bk) * g.sbk + (int64_t)(n0 + bn) * g.sbn] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int k = 2 * kk + (lane >> 5);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k][wr * 32 + (lane & 31)], Bs[k][wc * 32 + (lane & 31)], acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = n0 + wc * 32 + (lane & 31);
-    if (col >= g.N) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        float* c = C + (int64_t)row * g.scm + (int64_t)col * g.scn;
-        *c = g.alpha * acc[r] + (g.beta != 0.f ? g.beta * *c : 0.f);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // P = softmax over the last dim of S [B, H, Lq, L] (in place); mask uint8 [B, L], 1 = key ignored (-inf before the softmax).
@@ -275,16 +224,6 @@ inline unsigned grid_for(int64_t n, int block = 256, int cap = 16384) {
 }
 
 }  // namespace
-
-int launch_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn,
-                   int64_t scm, int64_t scn, int nb1, int nb2, int64_t sa1, int64_t sa2, int64_t sb1, int64_t sb2, int64_t sc1,
-                   int64_t sc2, float alpha, float beta, hipStream_t s) {
-    MST_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, "gemm_ex: bad arguments");
-    MST_CHECK_ARG((int64_t)nb1 * nb2 <= 65535, "gemm_ex: batch %d x %d exceeds the grid limit", nb1, nb2);
-    GemmExArgs g{A, B, C, M, N, K, nb2, sam, sak, sbk, sbn, scm, scn, sa1, sa2, sb1, sb2, sc1, sc2, alpha, beta};
-    gemm_ex_kernel<<<dim3((N + 63) / 64, (M + 63) / 64, nb1 * nb2), dim3(256), 0, s>>>(g);
-    return mst_check_launch("gemm_ex");
-}
 
 int launch_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_b, hipStream_t s) {
     softmax_rows_kernel<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(S, mask, rows, L, rows_per_b);

@@ -17,7 +17,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MST_HIP_LIB", _HERE / "libmst_hip.so"))
 
 F32, F16, BF16, F8E4M3 = 0, 1, 2, 3
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RELU, EPI_RESIDUAL, EPI_RESIDUAL_RELU = 0, 1, 2, 3, 4
 FUSION_TRANSFORMER, FUSION_LINEAR, FUSION_AVERAGE = 0, 1, 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
@@ -635,7 +635,7 @@ def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, kpad: 
 def conv_gemm(x: torch.Tensor, wg: torch.Tensor, bias: Optional[torch.Tensor], kh: int, kw: int, stride: int, pad: int, *,
               epilogue: int = EPI_BIAS, out: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Convolution of x [n,H,W,Cin] (NHWC fp32, Cin % 16 == 0) with the GEMM-form weight wg [Cout, Kpad] ((ky, kx, c) order) as an
-    implicit GEMM (mst_conv_gemm: no im2col matrix) -> [n*Ho*Wo, Cout].  out: the residual operand of EPI_RESIDUAL (updated in place)."""
+    implicit GEMM (mst_conv_gemm: no im2col matrix) -> [n*Ho*Wo, Cout].  out: the residual operand of EPI_RESIDUAL / EPI_RESIDUAL_RELU (updated in place)."""
     _dev(x, "conv_gemm")
     n, H, W, Cin = x.shape
     Cout, kpad = wg.shape

@@ -154,7 +154,8 @@ def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev):
 class ResNet(BasicClassifier):
     def __init__(self, in_ch, out_ch, spatial_dims=3, model=34, pretrained=False, kwargs_resnet={}, **kwargs):
         emb_ch = kwargs.pop("emb_ch", out_ch)
-        self.chunk_images = int(kwargs.pop("chunk_images", 16))       # build-specific: images per backbone pass (activation memory)
+        self.chunk_images = int(kwargs.pop("chunk_images", 128))      # build-specific: images per backbone pass (activation memory:
+        #                                                               0.4 GB for the stem's output at 128 images of 224 x 224)
         super().__init__(in_ch, out_ch, spatial_dims, **kwargs)
         self.attention_maps = []
         if spatial_dims != 2:
@@ -243,10 +244,9 @@ class ResNet(BasicClassifier):
                         wd, bd, kd = e["ds"]
                         idt = _conv(x=y, w=wd, b=bd, k=1, stride=s, pad=0, kpad=kd, epilogue=hip.EPI_BIAS)
                     else:
-                        idt = y.reshape(n * H * W, Cin).clone()
+                        idt = y.reshape(n * H * W, Cin)          # the unit's input is dead after it: the sum is formed in place
                     w3, b3, k3 = e["c3"]
-                    _conv(x=h1, w=w3, b=b3, k=1, stride=1, pad=0, kpad=k3, epilogue=hip.EPI_RESIDUAL, out=idt)
-                    hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))
+                    _conv(x=h1, w=w3, b=b3, k=1, stride=1, pad=0, kpad=k3, epilogue=hip.EPI_RESIDUAL_RELU, out=idt)
                     y = idt.view(n, Ho, Wo, w3.shape[0])
                     continue
                 h1 = _conv(x=y, w=w1, b=b1, k=3, stride=s, pad=1, kpad=k1, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, w1.shape[0])
@@ -254,10 +254,9 @@ class ResNet(BasicClassifier):
                     wd, bd, kd = e["ds"]
                     idt = _conv(x=y, w=wd, b=bd, k=1, stride=s, pad=0, kpad=kd, epilogue=hip.EPI_BIAS)
                 else:
-                    idt = y.reshape(n * H * W, Cin).clone()
+                    idt = y.reshape(n * H * W, Cin)              # the unit's input is dead after it: the sum is formed in place
                 w2, b2, k2 = e["c2"]
-                _conv(x=h1, w=w2, b=b2, k=3, stride=1, pad=1, kpad=k2, epilogue=hip.EPI_RESIDUAL, out=idt)      # identity + bn2(conv2(.))
-                hip.load().mst_act_fwd(hip.ptr(idt), hip.ptr(idt), idt.numel(), 1, hip.stream_of(idt))          # ReLU in place
+                _conv(x=h1, w=w2, b=b2, k=3, stride=1, pad=1, kpad=k2, epilogue=hip.EPI_RESIDUAL_RELU, out=idt)  # relu(identity + bn2(conv2(.)))
                 y = idt.view(n, Ho, Wo, w2.shape[0])
             outs.append(hip.avgpool_nhwc(y))
             if keep_last:

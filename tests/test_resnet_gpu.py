@@ -276,7 +276,7 @@ def test_conv_batchnorm_unit_forward_and_backward_match_torch(cin, cout, k, stri
 @pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw,kextra", [
     (5, 64, 64, 3, 1, 1, (16, 15), 0), (3, 64, 128, 3, 2, 1, (41, 37), 0), (5, 128, 256, 1, 2, 0, (35, 27), 0), (2, 16, 96, 3, 1, 1, (7, 5), 16),
     (1, 256, 64, 1, 1, 0, (3, 3), 0), (2, 80, 200, 3, 2, 1, (53, 49), 0), (7, 512, 512, 3, 1, 1, (2, 2), 0), (9, 16, 40, 3, 1, 1, (13, 11), 32)])
-@pytest.mark.parametrize("epi", ["bias", "relu", "residual"])
+@pytest.mark.parametrize("epi", ["bias", "relu", "residual", "residual_relu"])
 def test_implicit_gemm_convolution_equals_im2col_gemm_and_torch(n, cin, cout, k, stride, pad, hw, kextra, epi):
     """mst_conv_gemm gathers the A operand the im2col matrix would hold, in the same k order and tiles: bit-identical to
     mst_im2col_nhwc + mst_gemm (where that runs the same 128 x 128-tile kernel: more than 1,024 rows) for every epilogue, ragged row
@@ -293,10 +293,10 @@ def test_implicit_gemm_convolution_equals_im2col_gemm_and_torch(n, cin, cout, k,
     wg[:, :K] = w.permute(0, 2, 3, 1).reshape(cout, K)
     Ho, Wo = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
     res = torch.randn(n * Ho * Wo, cout, generator=g)
-    e = {"bias": hip.EPI_BIAS, "relu": hip.EPI_BIAS_RELU, "residual": hip.EPI_RESIDUAL}[epi]
+    e = {"bias": hip.EPI_BIAS, "relu": hip.EPI_BIAS_RELU, "residual": hip.EPI_RESIDUAL, "residual_relu": hip.EPI_RESIDUAL_RELU}[epi]
     xh, wh, bh = x.permute(0, 2, 3, 1).contiguous().cuda(), wg.cuda(), b.cuda()
-    o1 = res.cuda().clone() if epi == "residual" else None
-    o2 = res.cuda().clone() if epi == "residual" else None
+    o1 = res.cuda().clone() if epi.startswith("residual") else None
+    o2 = res.cuda().clone() if epi.startswith("residual") else None
     got = hip.conv_gemm(xh, wh, bh, k, k, stride, pad, epilogue=e, out=o1)
     via = hip.gemm(hip.im2col_nhwc(xh, k, k, stride, pad, kpad), wh, bh, epilogue=e, out=o2)
     assert got.shape == (n * Ho * Wo, cout)
@@ -305,7 +305,7 @@ def test_implicit_gemm_convolution_equals_im2col_gemm_and_torch(n, cin, cout, k,
     else:                                               # mst_gemm takes its 32 x 32-tile kernel here: another summation order
         assert rel_l2(got.cpu(), via.cpu()) < 1e-6
     want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(-1, cout)
-    want = F.relu(want) if epi == "relu" else want + res.double() if epi == "residual" else want
+    want = F.relu(want) if epi == "relu" else want + res.double() if epi == "residual" else F.relu(want + res.double()) if epi == "residual_relu" else want
     assert rel_l2(got.cpu(), want) < 1e-5
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, rel_l2
 from mst import synth
 from test_model_gpu import CASES, build
 
@@ -109,6 +109,34 @@ def test_fusion_variants_gradients(name):
     loss = torch.nn.functional.cross_entropy(model(src), target.cuda())
     loss.backward()
     _check_all(model, ref)
+
+
+@pytest.mark.parametrize("M,N,K,a_layout,b_layout", [
+    (257, 64, 257, "mk", "kn"), (64, 257, 260, "km", "kn"), (200, 384, 1028, "km", "nk"), (130, 70, 36, "mk", "nk"), (64, 64, 16, "mk", "kn"),
+    (384, 1536, 4112, "km", "kn"), (5, 3, 7, "mk", "kn"), (131, 67, 50, "km", "nk")])
+def test_strided_batched_gemm_every_staging_mode(M, N, K, a_layout, b_layout):
+    """mst_gemm_ex picks 16-byte operand loads along whichever dimension is contiguous when strides, base and extent allow and scalar
+    loads otherwise (k_gemm_ex.hip): every combination, ragged tiles, a K that is not a multiple of the K-step, both batch levels,
+    alpha / beta and element offsets, against fp64 matmul at the fp32 bar."""
+    from mst import hip
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    nb = (2, 3)
+    for off in (0, 1):                                  # off 1: bases no longer 16-byte aligned -> the scalar modes
+        A = torch.randn(nb[0], nb[1], *((M, K) if a_layout == "mk" else (K, M)), generator=g)
+        B = torch.randn(nb[0], nb[1], *((K, N) if b_layout == "kn" else (N, K)), generator=g)
+        C0 = torch.randn(nb[0], nb[1], M, N, generator=g)
+        A2 = A if a_layout == "mk" else A.transpose(-1, -2)
+        B2 = B if b_layout == "kn" else B.transpose(-1, -2)
+        want = 0.5 * (A2.double() @ B2.double()) + 2.0 * C0.double()
+        pad = lambda t: torch.cat([torch.zeros(off), t.reshape(-1)]).cuda()
+        Ad, Bd, Cd = pad(A), pad(B), pad(C0)
+        sa = (K, 1) if a_layout == "mk" else (1, M)
+        sb = (N, 1) if b_layout == "kn" else (1, K)
+        hip.gemm_ex(Ad, Bd, Cd, M, N, K, sa=sa, sb=sb, sc=(N, 1), nb=nb, ba=(nb[1] * M * K, M * K), bb=(nb[1] * K * N, K * N),
+                    bc=(nb[1] * M * N, M * N), alpha=0.5, beta=2.0, offs=(off, off, off))
+        got = Cd[off:].view(nb[0], nb[1], M, N).cpu()
+        assert rel_l2(got, want) < 2e-6
+        assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
 
 
 def test_features_path_frozen_encoder_and_an_optimizer_step():

@@ -23,6 +23,12 @@ def timeit(f, it=20):
 
 def main():
     n = 128
+    if "--only-model" not in sys.argv:
+        layers(n)
+    model()
+
+
+def layers(n):
     print(f"{'layer':34s} {'im2col+gemm ms':>15s} {'implicit ms':>12s} {'TFLOP/s':>8s}")
     for name, cin, cout, k, s, hw in [("layer1 3x3 64->64 56x56", 64, 64, 3, 1, 56), ("layer2 3x3 s2 64->128", 64, 128, 3, 2, 56),
                                       ("layer2 3x3 128->128 28x28", 128, 128, 3, 1, 28), ("layer3 3x3 256->256 14x14", 256, 256, 3, 1, 14),
@@ -37,6 +43,9 @@ def main():
         ho = (hw + 2 * pad - k) // s + 1
         fl = 2.0 * n * ho * ho * cout * K
         print(f"{name:34s} {t0:15.3f} {t1:12.3f} {fl / t1 / 1e9:8.1f}")
+
+
+def model():
     import warnings
     from mst import synth
     from mst.models import ResNetSliceTrans
@@ -46,7 +55,7 @@ def main():
     m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
     m = m.cuda().eval()
     src = torch.randn(4, 1, 32, 224, 224, device="cuda")
-    for mode in ("1", "0"):
+    for mode in (("0",) if "--only-model" in sys.argv else ("1", "0")):
         os.environ["MST_CONV_IM2COL"] = mode
         with torch.no_grad():
             t = timeit(lambda: m(src), it=5)
