@@ -52,7 +52,7 @@ __global__ void softmax_rows_bwd_kernel(const float* __restrict__ P, float* __re
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm backward.  One wave per row at a time, waves stride over the rows; d gamma / d beta partial sums live in registers
-// (column c = lane + 64 i, i < CI) and are added to the fp32 outputs with one atomic per column per wave.
+// (column c = lane + 64 i, i < CI), meet in LDS at the end and are added to the fp32 outputs with one atomic per column per workgroup.
 //   dx[row] = (dres ? dres[row] : 0) + rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),   dyg = dy * gamma
 template <int CI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ gamma,
@@ -113,13 +113,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
+    // the four waves' partial sums meet in LDS; one atomic per column per workgroup
+    __shared__ float red[4][2][CI * 64];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < CI; ++i) {
-        const int c = lane + 64 * i;
-        if (c < cols) {
-            if (dgamma) atomicAdd(dgamma + c, gsum[i]);
-            if (dbeta) atomicAdd(dbeta + c, bsum[i]);
-        }
+        red[wave][0][lane + 64 * i] = gsum[i];
+        red[wave][1][lane + 64 * i] = bsum[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        if (dgamma) atomicAdd(dgamma + c, (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]));
+        if (dbeta) atomicAdd(dbeta + c, (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]));
     }
 }
 
@@ -143,17 +148,44 @@ __global__ void act_fwd_kernel(const float* __restrict__ h, float* __restrict__ 
     }
 }
 
-// out[j] += sum_i a[i][j] * (b ? b[i][j] : 1): thread per column, a block per chunk of rows.
-__global__ void colsum_kernel(const float* __restrict__ a, int64_t as, const float* __restrict__ b, int64_t bs, int64_t rows, int cols,
-                              int rows_per_block, float* __restrict__ out) {
+// out[j] += sum_i a[i][j] * (b ? b[i][j] : 1).  A 256-thread block owns 64 columns x a chunk of rows: 16 threads x float4 across the
+// columns (VEC) or 64 threads x 1, the other 16 (4) thread rows stride down the chunk; the partial sums meet in LDS and ONE atomic per
+// column per block goes out (the round-2 kernel ran one thread per column down 256 rows: 34 workgroups for a [4112, 384] bias gradient).
+template <bool VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t as, const float* __restrict__ b, int64_t bs, int64_t rows,
+                                                     int cols, int rows_per_block, float* __restrict__ out) {
     // row blocks on gridDim.x (2^31 - 1 blocks), column blocks on gridDim.y: the stem's BatchNorm sums of a 2 x 128 x 512^2 ResNet
-    // step have 16.8 M rows = 65,536 row blocks, one more than gridDim.y takes
+    // step have 16.8 M rows, more row blocks than gridDim.y takes
+    constexpr int CW = VEC ? 4 : 1, TX = 64 / CW, TY = 256 / TX;
+    __shared__ float red[TY][64 + 4];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < cols; c += gridDim.y * blockDim.x) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s = fmaf(a[r * as + c], b ? b[r * bs + c] : 1.f, s);
-        atomicAdd(out + c, s);
+    const int c = blockIdx.y * 64 + tx * CW;
+    float acc[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) acc[e] = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + ty; r < r1; r += TY) {
+            if (VEC) {
+                const float4 av = *reinterpret_cast<const float4*>(a + r * as + c);
+                const float4 bv = b ? *reinterpret_cast<const float4*>(b + r * bs + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+                acc[0] = fmaf(av.x, bv.x, acc[0]); acc[CW > 1 ? 1 : 0] = fmaf(av.y, bv.y, acc[CW > 1 ? 1 : 0]);
+                acc[CW > 2 ? 2 : 0] = fmaf(av.z, bv.z, acc[CW > 2 ? 2 : 0]); acc[CW > 3 ? 3 : 0] = fmaf(av.w, bv.w, acc[CW > 3 ? 3 : 0]);
+            } else {
+                acc[0] = fmaf(a[r * as + c], b ? b[r * bs + c] : 1.f, acc[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CW; ++e) red[ty][tx * CW + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = blockIdx.y * 64 + threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < TY; ++y) t += red[y][threadIdx.x];
+        if (cc < cols) atomicAdd(out + cc, t);
     }
 }
 
@@ -238,7 +270,8 @@ int launch_softmax_rows_bwd(const float* P, float* dP, int64_t rows, int L, floa
 int launch_layernorm_bwd(const float* x, int64_t xs, const float* gamma, const float* dy, int64_t dys, const float* dres, int64_t drs,
                          float* dx, int64_t dxs, float* dgamma, float* dbeta, int64_t rows, int cols, float eps, hipStream_t s) {
     MST_CHECK_ARG(cols > 0 && cols <= 2048, "layernorm_bwd: cols=%d unsupported (<= 2048)", cols);
-    const unsigned grid = (unsigned)(rows < 4 ? 1 : (rows / 4 < 2048 ? rows / 4 : 2048));
+    // four rows per wave at least, 1,024 workgroups at most: the d gamma / d beta atomics are per workgroup
+    const unsigned grid = (unsigned)(rows < 16 ? 1 : (rows / 16 < 1024 ? rows / 16 : 1024));
 #define LNB(CI) layernorm_bwd_kernel<CI><<<dim3(grid), dim3(256), 0, s>>>(x, xs, gamma, dy, dys, dres, drs, dx, dxs, dgamma, dbeta, rows, cols, eps)
     if (cols <= 128) LNB(2);
     else if (cols <= 384) LNB(6);
@@ -260,9 +293,19 @@ int launch_act_fwd(const float* h, float* y, int64_t n, int kind, hipStream_t s)
 }
 
 int launch_colsum(const float* a, int64_t as, const float* b, int64_t bs, int64_t rows, int cols, float* out, hipStream_t s) {
-    const int rpb = 256;
-    MST_CHECK_ARG(rows > 0 && cols > 0 && (rows + rpb - 1) / rpb < (1ll << 31) && (cols + 255) / 256 <= 65535, "colsum: rows=%lld cols=%d out of range", (long long)rows, cols);
-    colsum_kernel<<<dim3((unsigned)((rows + rpb - 1) / rpb), (cols + 255) / 256), dim3(256), 0, s>>>(a, as, b, bs, rows, cols, rpb, out);
+    MST_CHECK_ARG(rows > 0 && cols > 0, "colsum: rows=%lld cols=%d out of range", (long long)rows, cols);
+    const int cblocks = (cols + 63) / 64;
+    MST_CHECK_ARG(cblocks <= 65535, "colsum: cols=%d out of range", cols);
+    // enough blocks to fill the chip (about 2,048), chunks of at least 64 rows so that the atomics stay few
+    int64_t rpb = (rows * cblocks + 2047) / 2048;
+    rpb = rpb < 64 ? 64 : (rpb + 15) / 16 * 16;
+    const int64_t rblocks = (rows + rpb - 1) / rpb;
+    MST_CHECK_ARG(rblocks < (1ll << 31) && rpb < (1ll << 31), "colsum: rows=%lld out of range", (long long)rows);
+    const bool vec = cols % 4 == 0 && as % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+                     (!b || (bs % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0));
+    const dim3 grid((unsigned)rblocks, cblocks);
+    if (vec) colsum_kernel<true><<<grid, dim3(256), 0, s>>>(a, as, b, bs, rows, cols, (int)rpb, out);
+    else colsum_kernel<false><<<grid, dim3(256), 0, s>>>(a, as, b, bs, rows, cols, (int)rpb, out);
     return mst_check_launch("colsum");
 }
 

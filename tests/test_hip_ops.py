@@ -183,14 +183,29 @@ def test_gemm_falls_back_for_unaligned_operands(hip):
 
 
 def test_colsum_more_row_blocks_than_grid_y(hip):
-    """16.8 M rows (the stem BatchNorm sums of a 2 x 128 x 512^2 ResNet step) are 65,536 blocks of 256 rows -- one more
-    than gridDim.y takes; the row blocks now sit on gridDim.x."""
+    """16.8 M rows (the stem BatchNorm sums of a 2 x 128 x 512^2 ResNet step) were 65,536 blocks of 256 rows -- one more
+    than gridDim.y takes; the row blocks sit on gridDim.x (and their size now grows with the row count)."""
     rows, cols = 256 * 65536 + 3, 2
     a = torch.ones(rows, cols, device="cuda")
     a[:, 1] = 0.5
     out = torch.zeros(cols, device="cuda")
     hip.colsum(a, out)
     assert torch.allclose(out.cpu(), torch.tensor([float(rows), rows * 0.5]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols", [(4112, 384), (1, 5), (17, 64), (1000, 130), (70, 4100), (300001, 64), (33, 2)])
+@pytest.mark.parametrize("prod", [False, True])
+def test_colsum_vector_and_scalar_column_blocks(hip, rows, cols, prod):
+    """mst_colsum: 64-column blocks, float4 across the columns when cols % 4 == 0 (scalar otherwise), partial sums reduced in LDS; with and
+    without the second operand, accumulating onto what `out` holds."""
+    g = torch.Generator().manual_seed(rows + cols)
+    a = torch.randn(rows, cols, generator=g)
+    b = torch.randn(rows, cols, generator=g) if prod else None
+    out0 = torch.randn(cols, generator=g)
+    want = out0.double() + (a.double() * (b.double() if prod else 1.0)).sum(0)
+    out = out0.cuda()
+    hip.colsum(a.cuda(), out, b.cuda() if prod else None)
+    assert float((out.cpu() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max())) * max(1.0, rows ** 0.5 / 30)
 
 
 def test_gemm_rejects_bad_shapes(hip):
