@@ -34,14 +34,8 @@ constexpr int K_ROW = 144, K_TILE_BYTES = 64 * K_ROW;
 #ifndef ATTN_NO_DMA
 #define ATTN_DMA 1
 #endif
-// -DATTN_PIPE (needs ATTN_DMA): fragment reads in asm, four in flight behind counted lgkmcnt waits instead of the compiler's one
-// read per MFMA.  Measured 0.978 vs 0.970 ms: with four waves per SIMD the exposed LDS latency is already covered by the other
-// waves -- the loop is bound by issue slots and power, not by latency.  Off by default.
-#if defined(ATTN_PIPE) && !defined(ATTN_DMA)
-#undef ATTN_PIPE
-#endif
-#define ATTN_RD128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
-#define ATTN_RDTR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+// (Tried in round 2 and removed in round 3: fragment reads in asm, four in flight behind counted lgkmcnt waits instead of the compiler's
+// one read per MFMA -- 0.978 vs 0.970 ms: with four waves per SIMD the exposed LDS latency is already covered by the other waves.)
 
 template <typename T>
 __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const char* p_hi) {
@@ -207,11 +201,8 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #pragma unroll
             for (int j = 0; j < 8; ++j) bq[ds][j] = (T)((float)bq[ds][j] * LOG2E);
     }
-    vec8 kone, qneg;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) kone[j] = qneg[j] = (T)0.f;
-    if (h2 == 0) kone[0] = (T)1.f;
-    float r_ref = 0.f, l_run = 0.f;
+    float r_ref = 0.f, l_run = 0.f;                       // (the reference MFMA's operands are rebuilt from r_ref where a classic tile needs them:
+    //                                                       eight registers that the fast loop does not carry)
     constexpr float RT = 8.0f;
 
     const int nt = (N + 63) >> 6;
@@ -224,16 +215,36 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #endif
     __syncthreads();
 
-    // one KV tile; MASK = the ragged last tile (keys >= N get -inf).  Peeled so the 32 selects per tile that the
-    // compiler otherwise if-converts into EVERY iteration stay out of the steady-state loop.
-    auto tile_step = [&](auto mask_tag, int t) {
+    // FAST mode.  The reference point only exists to keep exp2 inside the range of its type: when the first tile's maxima are small
+    // (|max| <= TH0 in the log2 domain for every query of the wave) the reference stays 0 and the later tiles run WITHOUT the running
+    // maximum (32 v_max + a cross-half swap) and WITHOUT the reference MFMA of each score chain; the tile's own row sum guards the
+    // range instead (one compare: sum < GUARD means every p < GUARD), and a tile that fails it is recomputed the classic way and the
+    // wave stays classic from there on.  Softmax is invariant to the reference point, so both modes give the same result up to
+    // rounding; bf16 has fp32's exponent range (GUARD 2^100), fp16 needs p <= 65504 (GUARD 2^15, TH0 8 as RT).
+    constexpr float TH0 = std::is_same<T, f16_t>::value ? 8.0f : 60.0f;
+    constexpr float GUARD = std::is_same<T, f16_t>::value ? 32768.0f : 1.2676506e30f;
+    bool fast = false;                                   // wave-uniform
+#ifdef ATTN_NO_FAST
+    constexpr bool fast_allowed = false;
+#else
+    constexpr bool fast_allowed = true;
+#endif
+
+    // one KV tile; MASK = the ragged last tile (keys >= N get -inf; its upper 32 keys are skipped altogether when none is valid).
+    // Peeled so the 32 selects per tile that the compiler otherwise if-converts into EVERY iteration stay out of the steady-state loop.
+    // A FAST tile whose guard trips returns false BEFORE it has touched l_run / oT or reached its barrier; the caller re-enters the same
+    // tile in classic mode with skip_dma (the next tile's DMA is already in flight).  The recomputation lives outside the fast loop so
+    // that the loop's register allocation is its own (with it inside, the Q fragments were spilled and their reloads' vmcnt(0) waited
+    // for the DMA of the next tile: 1.64 ms instead of 0.95).
+    auto tile_step = [&](auto mask_tag, auto fast_tag, int t, bool skip_dma) -> bool {
         constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int buf = t & 1;
 #ifndef ATTN_ABL_NO_GLOAD
 #ifdef ATTN_DMA
-        if (t + 1 < nt) dma(t + 1, buf ^ 1);             // that buffer was last read in tile t-1: every wave is behind its barrier
+        if (t + 1 < nt && !skip_dma) dma(t + 1, buf ^ 1);  // that buffer was last read in tile t-1: every wave is behind its barrier
 #else
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt && !skip_dma) gload(t + 1);
 #endif
 #endif
         if (wave_active) {
@@ -241,156 +252,124 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
             const char* Vb = Vs + buf * KV_TILE_BYTES;
             f32x16 s[2];
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef ATTN_PIPE
-            {
-                const int kbase = (int)(size_t)(Kb - smem);
-                int ka_addr[4];
+            const bool upper = !MASK || (t * 64 + 32 < N);           // wave-uniform: the tile's keys 32..63 hold a valid key
+            auto scores = [&](bool with_ref) {
+                vec8 kone, qneg;
+                if (with_ref) {
 #pragma unroll
-                for (int ds = 0; ds < 4; ++ds) ka_addr[ds] = k_off4[ds] + kbase;
-                u32x4 ka[4];
-                ATTN_RD128(ka[0], ka_addr[0], 0);
-                ATTN_RD128(ka[1], ka_addr[1], 0);
-                ATTN_RD128(ka[2], ka_addr[2], 0);
-                ATTN_RD128(ka[3], ka_addr[3], 0);
-                s[0] = mfma32(kone, qneg, zero16);       // -r[q] in every key row
-                s[1] = mfma32(kone, qneg, zero16);
-#define ATTN_QK(I, WAITN)                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" : "+v"(ka[(I) & 3])::"memory");                       \
-    s[(I) >> 2] = mfma32(__builtin_bit_cast(vec8, ka[(I) & 3]), bq[(I) & 3], s[(I) >> 2]);             \
-    if ((I) + 4 < 8) ATTN_RD128(ka[(I) & 3], ka_addr[(I) & 3], 4096);
-                ATTN_QK(0, 3) ATTN_QK(1, 3) ATTN_QK(2, 3) ATTN_QK(3, 3) ATTN_QK(4, 3) ATTN_QK(5, 2) ATTN_QK(6, 1) ATTN_QK(7, 0)
-#undef ATTN_QK
-            }
-#else
+                    for (int j = 0; j < 8; ++j) kone[j] = qneg[j] = (T)0.f;
+                    if (h2 == 0) {
+                        kone[0] = (T)1.f;
+                        qneg[0] = (T)(-r_ref);           // 16-bit representable by construction
+                    }
+                }
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                s[kb] = mfma32(kone, qneg, zero16);      // -r[q] in every key row
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (MASK && kb == 1 && !upper) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[1][r] = -INFINITY;
+                        continue;
+                    }
+                    s[kb] = with_ref ? mfma32(kone, qneg, zero16) : zero16;      // -r[q] in every key row
 #ifndef ATTN_ABL_NO_QK
 #pragma unroll
-                for (int ds = 0; ds < 4; ++ds) {
+                    for (int ds = 0; ds < 4; ++ds) {
 #ifdef ATTN_DMA
-                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_off4[ds] + kb * 4096);
+                        const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_off4[ds] + kb * 4096);
 #else
-                    const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
+                        const vec8 a = *reinterpret_cast<const vec8*>(Kb + k_lane_off + kb * 32 * K_ROW + ds * 32);
 #endif
-                    s[kb] = mfma32(a, bq[ds], s[kb]);
+                        s[kb] = mfma32(a, bq[ds], s[kb]);
+                    }
+#endif
                 }
-#endif
-            }
-#endif
-            if constexpr (MASK) {
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                            if (key >= N) s[kb][r] = -INFINITY;
+                        }
+                }
+            };
+            float lsum;
+            auto exps = [&]() {                          // s <- p = exp2(s), lsum = this lane's partial row sum
+                lsum = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                        if (key >= N) s[kb][r] = -INFINITY;
-                    }
-            }
-#ifdef ATTN_ABL_NO_MAX
-            float mx = 0.f;
-            asm volatile("" : "+v"(mx));
-            if (t < 0) {
-#else
-            float mx = s[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-#ifdef ATTN_BPERMUTE
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#else
-            {   // the other half of the query's keys sits 32 lanes away: one v_permlane32_swap instead of an LDS round trip
-                // (ds_bpermute + a wait for every outstanding LDS operation) in the middle of every tile
-                const unsigned mu = __float_as_uint(mx);
-                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-#endif
-            if (t == 0 || !__all(mx <= RT)) {            // rare after the first tiles: move the reference point
-#endif
-                const bool mv = (t == 0) || (mx > RT);
-                const float r_new = mv ? (float)(T)(r_ref + mx) : r_ref;   // 16-bit representable
-                const float delta = r_new - r_ref;
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                r_ref = r_new;
-                if (h2 == 0) qneg[0] = (T)(-r_new);
-                l_run *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    oT[0][r] *= alpha;
-                    oT[1][r] *= alpha;
-                    s[0][r] -= delta;
-                    s[1][r] -= delta;
-                }
-            }
-            float lsum = 0.f;
-#ifdef ATTN_PK_SUM
-            // row sums by packed adds (v_pk_add_f32: two values per instruction): 16 instead of 32 vector instructions per tile
-            typedef __attribute__((ext_vector_type(2))) float f32x2;
-            f32x2 l2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                    s[kb][r] = p0;
-                    s[kb][r + 1] = p1;
-                    l2 += f32x2{p0, p1};
-                }
-            lsum = l2[0] + l2[1];
-#else
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
 #ifdef ATTN_ABL_NO_EXP
-                    float p = s[kb][r];
-                    asm volatile("" : "+v"(p));
+                        float p = s[kb][r];
+                        asm volatile("" : "+v"(p));
 #else
-                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                        const float p = __builtin_amdgcn_exp2f(s[kb][r]);
 #endif
-                    s[kb][r] = p;
+                        s[kb][r] = p;
 #ifndef ATTN_ABL_NO_SUM
-                    lsum += p;                           // one chain: four partial sums measured 3 % slower (registers)
+                        lsum += p;                       // one chain: four partial sums measured 3 % slower (registers)
 #endif
+                    }
+            };
+            auto classic = [&]() {                       // running maximum, reference point, probabilities
+#ifdef ATTN_ABL_NO_MAX
+                float mx = 0.f;
+                asm volatile("" : "+v"(mx));
+                if (t < 0) {
+#else
+                float mx = s[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+#ifdef ATTN_BPERMUTE
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#else
+                {   // the other half of the query's keys sits 32 lanes away: one v_permlane32_swap instead of an LDS round trip
+                    // (ds_bpermute + a wait for every outstanding LDS operation) in the middle of every tile
+                    const unsigned mu = __float_as_uint(mx);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
 #endif
+                if (t == 0 && fast_allowed && __all(fabsf(mx) <= TH0)) {
+                    fast = true;                          // the reference point stays 0
+                } else if (t == 0 || !__all(mx <= RT)) {   // rare after the first tiles: move the reference point
+#endif
+                    const bool mv = (t == 0) || (mx > RT);
+                    const float r_new = mv ? (float)(T)(r_ref + mx) : r_ref;   // 16-bit representable
+                    const float delta = r_new - r_ref;
+                    const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // t > 0: the reference only moves up (t = 0: nothing accumulated yet, and 2^-delta may be inf)
+                    r_ref = r_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        oT[0][r] *= alpha;
+                        oT[1][r] *= alpha;
+                        s[0][r] -= delta;
+                        s[1][r] -= delta;
+                    }
+                }
+                exps();
+            };
+            if constexpr (FAST) {
+                scores(false);
+                exps();
+                if (!__all(lsum < GUARD)) return false;  // out of range without a maximum: this tile again, the classic way
+            } else {
+                scores(true);                            // (after a tripped guard the reference point is still 0)
+                classic();
+            }
             l_run += lsum;
             vec8 pf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[ks][j] = (T)s[ks >> 1][(ks & 1) * 8 + j];
-#ifdef ATTN_PIPE
-            {
-                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-                const int vbase = (int)(size_t)(Vb - smem) + v_lane_off;
-                int va_addr[2];
-#pragma unroll
-                for (int db = 0; db < 2; ++db) va_addr[db] = vbase + (((db * 4 + vchunk) ^ vsw) << 4);
-                u32x2 vl[4], vh[4];
-#define ATTN_VRD(J, KSOFF)                                             \
-    ATTN_RDTR(vl[(J) & 3], va_addr[(J) & 1], KSOFF);                   \
-    ATTN_RDTR(vh[(J) & 3], va_addr[(J) & 1], (KSOFF) + 1024);
-                ATTN_VRD(0, 0) ATTN_VRD(1, 0) ATTN_VRD(2, 2048) ATTN_VRD(3, 2048)
-#define ATTN_PV(J, WAITN, NEXTOFF)                                                                           \
-    {                                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(" #WAITN ")" : "+v"(vl[(J) & 3]), "+v"(vh[(J) & 3])::"memory");      \
-        union { struct { u32x2 lo, hi; } p; vec8 v; } uu;                                                    \
-        uu.p.lo = vl[(J) & 3];                                                                               \
-        uu.p.hi = vh[(J) & 3];                                                                               \
-        oT[(J) & 1] = mfma32(uu.v, pf[(J) >> 1], oT[(J) & 1]);                                               \
-        if ((J) + 4 < 8) { ATTN_VRD((J) + 4, NEXTOFF) }                                                      \
-    }
-                ATTN_PV(0, 6, 4096) ATTN_PV(1, 6, 4096) ATTN_PV(2, 6, 6144) ATTN_PV(3, 6, 6144)
-                ATTN_PV(4, 6, 0) ATTN_PV(5, 4, 0) ATTN_PV(6, 2, 0) ATTN_PV(7, 0, 0)
-#undef ATTN_PV
-#undef ATTN_VRD
-            }
-#else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (MASK && ks >= 2 && !upper) continue;  // p = 0 for all of those keys
 #ifdef ATTN_ABL_NO_PV
                 asm volatile("" : "+v"(oT[0]), "+v"(oT[1]) : "v"(pf[ks]));
 #else
@@ -402,7 +381,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 }
 #endif
             }
-#endif
         }
 #ifndef ATTN_ABL_NO_GLOAD
 #ifdef ATTN_DMA
@@ -416,10 +394,30 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
 #ifndef ATTN_ABL_NO_BARRIER
         __syncthreads();
 #endif
+        return true;
     };
     const int nt_full = (N & 63) ? nt - 1 : nt;
-    for (int t = 0; t < nt_full; ++t) tile_step(std::false_type{}, t);
-    if (nt_full < nt) tile_step(std::true_type{}, nt - 1);
+    const std::false_type FULL{}, CLASSIC{};
+    const std::true_type RAGGED{}, FASTM{};
+    if (nt_full > 0) tile_step(FULL, CLASSIC, 0, false);  // the first tile always computes its maxima: it decides the mode
+    else tile_step(RAGGED, CLASSIC, 0, false);
+    int t = 1;
+    bool resume = false;                                 // the classic loop re-enters a tile whose DMA has been issued
+    if (fast) {
+        for (; t < nt_full; ++t)
+            if (!tile_step(FULL, FASTM, t, false)) { resume = true; break; }
+#ifdef ATTN_FAST_RAGGED
+        if (!resume && t < nt) {
+            if (tile_step(RAGGED, FASTM, t, false)) t = nt;
+            else resume = true;
+        }
+#endif
+    }
+    for (; t < nt_full; ++t) {
+        tile_step(FULL, CLASSIC, t, resume);
+        resume = false;
+    }
+    if (t < nt) tile_step(RAGGED, CLASSIC, t, resume);
 
     if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

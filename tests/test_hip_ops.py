@@ -404,6 +404,35 @@ def test_attention_online_softmax_rescale_branch(hip, dt):
     assert scaled_err(got, ref) < {"bf16": 1.2e-2, "fp16": 2e-3, "fp32": 2e-5}[dt]
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["spike_first_tile", "spike_late_tile", "all_very_negative", "late_tile_above_first_by_20", "ragged_26_of_64"])
+def test_attention_fast_mode_guard_and_fallback(hip, dt, case):
+    """The 16-bit kernel drops the running maximum (and the reference MFMA) after a first tile with small maxima and guards the range
+    with the tile's row sum (k_attn16.hip): scores that leave the range of exp2 / of the operand type in the first tile (classic mode
+    from the start), in a late tile (that tile is recomputed the classic way), far below zero, or moderately above the first tile
+    (fp16: guard trips, bf16: stays fast) must all give the softmax of the reference."""
+    tdt = DT[dt]
+    n, N, heads = 2, {"ragged_26_of_64": 64 * 3 + 26}.get(case, 400), 2
+    qkv = rnd((n * N, 3 * heads * 64), 77, 0.3)
+    E = heads * 64
+    qkv[:, :E] = qkv[:, :E].abs() * 0.3 + 0.1                     # positive queries: a key's scale steers its score for every query
+    if case == "spike_first_tile":
+        qkv[5, E:2 * E] = 12.0                                     # ~190 in the log2 domain: beyond exp2's range without a reference
+        qkv[N + 40, E:2 * E] = 12.0
+    elif case == "spike_late_tile":
+        qkv[333, E:2 * E] = 12.0
+        qkv[N + 200, E:2 * E] = 12.0
+    elif case == "all_very_negative":
+        qkv[:, E:2 * E] = -(qkv[:, E:2 * E].abs() + 8.0)           # every score ~ -100 natural: exp2 underflows without a reference
+    elif case == "late_tile_above_first_by_20":
+        qkv[300, E:2 * E] = 1.6                                    # ~ +25 in the log2 domain
+    qkv = qkv.to(tdt)
+    ref, _ = _attn_ref(qkv.float(), n, N, heads, 64)
+    got = hip.attention(qkv.cuda(), n, N, heads)
+    assert torch.isfinite(got).all()
+    assert scaled_err(got, ref) < {"bf16": 1.2e-2, "fp16": 2e-3}[dt]
+
+
 # ---------------------------------------------------------------------------------------------------
 def test_pos_embed_interp_matches_reference_fixture(hip):
     g = load_golden("ops")
