@@ -37,6 +37,19 @@ constexpr int K_ROW = 144, K_TILE_BYTES = 64 * K_ROW;
 // (Tried in round 2 and removed in round 3: fragment reads in asm, four in flight behind counted lgkmcnt waits instead of the compiler's
 // one read per MFMA -- 0.978 vs 0.970 ms: with four waves per SIMD the exposed LDS latency is already covered by the other waves.)
 
+// c + a.x + a.y for a pair of 16-bit values (v_dot2_f32_bf16 / v_dot2_f32_f16 against (1, 1)): the row sums of the ROUNDED probabilities,
+// two per instruction
+__device__ __forceinline__ float sum2(bf16_t x, bf16_t y, float c) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    const v2 a = {x, y}, one = {(bf16_t)1.0f, (bf16_t)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(a, one, c, false);
+}
+__device__ __forceinline__ float sum2(f16_t x, f16_t y, float c) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    const v2 a = {x, y}, one = {(f16_t)1.0f, (f16_t)1.0f};
+    return __builtin_amdgcn_fdot2(a, one, c, false);
+}
+
 template <typename T>
 __device__ __forceinline__ typename V8<T>::type tr_pair(const char* p_lo, const char* p_hi) {
     typedef typename V8<T>::type vec8;
@@ -294,7 +307,8 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 }
             };
             float lsum;
-            auto exps = [&]() {                          // s <- p = exp2(s), lsum = this lane's partial row sum
+            vec8 pf[4];
+            auto exps = [&]() {                          // s <- p = exp2(s), pf = p in 16 bits, lsum = this lane's partial row sum
                 lsum = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -307,10 +321,22 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                         const float p = __builtin_amdgcn_exp2f(s[kb][r]);
 #endif
                         s[kb][r] = p;
-#ifndef ATTN_ABL_NO_SUM
+#if !defined(ATTN_ABL_NO_SUM) && !defined(ATTN_SUM_DOT2)
                         lsum += p;                       // one chain: four partial sums measured 3 % slower (registers)
 #endif
                     }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[ks][j] = (T)s[ks >> 1][(ks & 1) * 8 + j];
+#if !defined(ATTN_ABL_NO_SUM) && defined(ATTN_SUM_DOT2)
+                // -DATTN_SUM_DOT2: the sum of the probabilities as the P.V MFMA sees them (rounded to 16 bits), two per v_dot2: 16 instructions
+                // instead of 32 adds -- measured 1.5 % SLOWER (0.958 vs 0.944 ms), off
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) lsum = sum2(pf[ks][j], pf[ks][j + 1], lsum);
+#endif
             };
             auto classic = [&]() {                       // running maximum, reference point, probabilities
 #ifdef ATTN_ABL_NO_MAX
@@ -362,11 +388,6 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(ATTN_WAVES_
                 classic();
             }
             l_run += lsum;
-            vec8 pf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[ks][j] = (T)s[ks >> 1][(ks & 1) * 8 + j];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (MASK && ks >= 2 && !upper) continue;  // p = 0 for all of those keys
