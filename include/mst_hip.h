@@ -257,6 +257,16 @@ int mst_block_fused_s(float* x, const void* attn_out, void* xn_out, int dtype, c
  * mst_axpby_cols: y[r][c] = alpha * x[r][c] * (g ? g[c] : 1) + beta * y[r][c].
  * mst_im2col14: vol [n,H,W] -> col fp32 [n*Np, 196], the 14 x 14 patches as rows (patch_embed.py:68-81; d W = dX^T . col).
  * mst_pos_embed_interp_bwd: dpos [M*M, E] += adjoint of mst_pos_embed_interp (antialias = 0) applied to dout [gh*gw, E]. */
+/* Mixed-precision training step (the reference trains under precision='16-mixed': scripts/main_train.py:110-123): activations, weights and
+ * gradients stay fp32 in memory, the products of nn.Linear run on 16-bit MFMA operands with fp32 accumulation.
+ * mst_cvt16: out[r][c] = T(scale * x[r][c]) for r < rows, c < cols (transpose = 0; cols, ldx, ldo multiples of 4), or the TRANSPOSED image
+ *   out[c][r], r < rows_pad, zero-filled for r >= rows (transpose = 1): both operands of d weight = dY^T . X contiguous along the token index.
+ * mst_gemm16_splitk: Cpart[z] (fp32 [M, N], split_stride elements apart) = A[:, z Kc:(z+1) Kc] . W[:, z Kc:(z+1) Kc]^T, Kc = K / splits a
+ *   multiple of 64, N of 128; the caller sums the partial products (mst_colsum over [splits, M * N]). */
+int mst_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int out_dtype, int64_t ldo, int transpose,
+              int64_t rows_pad, mst_stream_t stream);
+int mst_gemm16_splitk(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int K,
+                      int splits, int64_t split_stride, mst_stream_t stream);
 int mst_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* strides, int nb1, int nb2,
                 float alpha, float beta, mst_stream_t stream);
 int mst_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_batch, mst_stream_t stream);

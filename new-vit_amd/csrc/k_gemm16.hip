@@ -27,9 +27,13 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
                                                      const float* __restrict__ bias, OutT* C,
                                                      int64_t ldc, int M, int N, int K,
                                                      const float* __restrict__ gamma, float col_scale,
-                                                     int scale_cols, int tiles_n, int nwg) {
+                                                     int scale_cols, int tiles_n, int nwg, int64_t split_stride) {
     typedef typename V8<T>::type vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // split-K (launch_gemm16_splitk): blockIdx.y owns the K columns [y K, (y + 1) K) of both operands and its own fp32 partial C
+    A += (int64_t)blockIdx.y * K;
+    W += (int64_t)blockIdx.y * K;
+    C += (int64_t)blockIdx.y * split_stride;
     char* const As = smem;                   // [2][128][64] T
     char* const Ws = smem + 2 * TILE_BYTES;  // [2][128][64] T
 
@@ -168,8 +172,21 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
     const int nwg = tiles_m * tiles_n;
     kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc,
-                                                       (int)M, N, K, gamma, col_scale, scale_cols, tiles_n, nwg);
+                                                       (int)M, N, K, gamma, col_scale, scale_cols, tiles_n, nwg, 0);
     return mst_check_launch("gemm16");
+}
+
+template <typename T>
+int launch_split(const void* A, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int Kc, int splits,
+                 int64_t split_stride, hipStream_t s) {
+    static mst_lds_once lds_once;
+    auto kern = gemm16_kernel<T, MST_EPI_BIAS, float>;
+    mst_allow_lds((const void*)kern, 4 * TILE_BYTES, &lds_once);
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
+    const int nwg = tiles_m * tiles_n;
+    kern<<<dim3(nwg, splits), dim3(256), 4 * TILE_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, nullptr, Cpart, ldc, (int)M, N, Kc, nullptr,
+                                                               1.f, 0, tiles_n, nwg, split_stride);
+    return mst_check_launch("gemm16_splitk");
 }
 
 template <typename T>
@@ -195,6 +212,23 @@ int dispatch(const void* A, int64_t lda, const void* W, int64_t ldw, const float
 }
 
 }  // namespace
+
+// Cpart[z] = A[:, z Kc : (z + 1) Kc] . W[:, z Kc : (z + 1) Kc]^T for z < splits (fp32 partial products, split_stride elements apart; the caller
+// sums them: mst_colsum over a [splits, M * N] view).  The shape of d weight = dY^T . X: a small [N_out, N_in] output reduced over
+// thousands of token rows, which one workgroup per output tile would walk on a handful of CUs.
+int launch_gemm16_splitk(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int K,
+                         int splits, int64_t split_stride, hipStream_t s) {
+    MST_CHECK_ARG(A && W && Cpart && M > 0 && splits > 0 && splits <= 65535, "gemm16_splitk: bad arguments");
+    MST_CHECK_ARG(K % splits == 0 && (K / splits) % BK == 0, "gemm16_splitk: K=%d must split into %d multiples of %d", K, splits, BK);
+    MST_CHECK_ARG(N > 0 && N % BN == 0, "gemm16_splitk: N=%d must be a multiple of %d", N, BN);
+    MST_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)Cpart & 15) == 0,
+                  "gemm16_splitk: lda/ldw must be multiples of 8, ldc of 4, bases 16-byte aligned");
+    MST_CHECK_ARG(split_stride >= M * ldc && split_stride % 4 == 0, "gemm16_splitk: split_stride");
+    if (dt == MST_BF16) return launch_split<bf16_t>(A, lda, W, ldw, Cpart, ldc, M, N, K / splits, splits, split_stride, s);
+    if (dt == MST_F16) return launch_split<f16_t>(A, lda, W, ldw, Cpart, ldc, M, N, K / splits, splits, split_stride, s);
+    mst_set_error("gemm16_splitk: bad operand dtype %d", dt);
+    return MST_EINVAL;
+}
 
 int launch_gemm16(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, const float* bias,
                   void* C, int cdt, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,

@@ -177,6 +177,14 @@ int mst_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, c
     return launch_gemm_ex(A, B, C, M, N, K, st[0], st[1], st[2], st[3], st[4], st[5], nb1, nb2, st[6], st[7], st[8], st[9], st[10],
                           st[11], alpha, beta, (hipStream_t)stream);
 }
+int mst_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int out_dtype, int64_t ldo, int transpose,
+              int64_t rows_pad, mst_stream_t stream) {
+    return launch_cvt16(x, ldx, rows, cols, scale, out, out_dtype, ldo, transpose, rows_pad, (hipStream_t)stream);
+}
+int mst_gemm16_splitk(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int K,
+                      int splits, int64_t split_stride, mst_stream_t stream) {
+    return launch_gemm16_splitk(A, ab_dtype, lda, W, ldw, Cpart, ldc, M, N, K, splits, split_stride, (hipStream_t)stream);
+}
 int mst_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_batch, mst_stream_t stream) {
     MST_CHECK_ARG(S && rows > 0 && L > 0 && rows_per_batch > 0, "softmax_rows: bad arguments");
     return launch_softmax_rows(S, mask, rows, L, rows_per_batch, (hipStream_t)stream);

@@ -166,6 +166,10 @@ int launch_gemm16_mid(const void* A, int dt, int64_t lda, const void* W, int64_t
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                   float* C, int64_t ldc, int64_t M, int N, int K, int epi, const float* gamma,
                   float col_scale, int scale_cols, hipStream_t s);
+int launch_gemm16_splitk(const void* A, int dt, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int K,
+                         int splits, int64_t split_stride, hipStream_t s);
+int launch_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int dt, int64_t ldo, int transpose,
+                 int64_t rows_pad, hipStream_t s);
 int launch_conv_gemm32(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, int64_t ldw,
                        const float* bias, float* out, int64_t ldc, int Cout, int Kpad, int epi, const float* gamma, hipStream_t s);
 bool gemm32_small_applicable(int64_t M, int N, int K);

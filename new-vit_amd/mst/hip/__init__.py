@@ -82,6 +82,8 @@ SIGNATURES = {
     "mst_im2col14": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_pos_embed_interp_bwd": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp]),
     "mst_im2col_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mst_cvt16": (_i, [_vp, _i64, _i64, _i, _f, _vp, _i, _i64, _i, _i64, _vp]),
+    "mst_gemm16_splitk": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i64, _vp]),
     "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -552,6 +554,32 @@ def gemm_ex(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K
     _check(load().mst_gemm_ex(A.data_ptr() + 4 * offs[0], B.data_ptr() + 4 * offs[1], C.data_ptr() + 4 * offs[2], M, N, K, st,
                               nb[0], nb[1], alpha, beta, stream_of(C)), "mst_gemm_ex")
     return C
+
+
+def cvt16(x: torch.Tensor, dtype: torch.dtype, *, transpose: bool = False, rows_pad: Optional[int] = None, scale: float = 1.0) -> torch.Tensor:
+    """mst_cvt16: the 16-bit image of an fp32 matrix [rows, cols] -- the same layout, or transposed [cols, rows_pad] with zero columns for
+    rows .. rows_pad (operands of the mixed-precision training GEMMs)."""
+    _dev(x, "cvt16")
+    rows, cols = x.shape
+    if transpose:
+        rp = rows_pad or rows
+        out = torch.empty((cols, rp), dtype=dtype, device=x.device)
+        _check(load().mst_cvt16(ptr(x), cols, rows, cols, scale, ptr(out), dt_of(out), rp, 1, rp, stream_of(x)), "mst_cvt16")
+        return out
+    out = torch.empty((rows, cols), dtype=dtype, device=x.device)
+    _check(load().mst_cvt16(ptr(x), cols, rows, cols, scale, ptr(out), dt_of(out), cols, 0, rows, stream_of(x)), "mst_cvt16")
+    return out
+
+
+def gemm16_splitk(a: torch.Tensor, w: torch.Tensor, splits: int) -> torch.Tensor:
+    """mst_gemm16_splitk: partial products [splits, M, N] fp32 of a [M, K] . w [N, K]^T over `splits` equal K ranges (16-bit operands)."""
+    _dev(a, "gemm16_splitk")
+    _dev(w, "gemm16_splitk")
+    M, K = a.shape
+    N = w.shape[0]
+    part = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    _check(load().mst_gemm16_splitk(ptr(a), dt_of(a), K, ptr(w), K, ptr(part), N, M, N, K, splits, M * N, stream_of(a)), "mst_gemm16_splitk")
+    return part
 
 
 def softmax_rows(S: torch.Tensor, mask: Optional[torch.Tensor], rows_per_batch: int):

@@ -12,6 +12,9 @@ Build-specific (keyword-only, all optional) controls -- none changes the maths o
                   TF32-class path (reference GPUs run TF32: main_predict.py:195), fp32 is exact.
                   'fp8' (BASELINE configs[4]): the blocks' four linear layers with OCP e4m3 operands and
                   per-tensor absmax scales (dynamic for activations), everything else as in bf16 mode.
+  train_precision 'fp32' (default) | 'bf16' | 'fp16': MFMA operand type of the blocks' nn.Linear products in the TRAINING step
+                  (forward and backward; fp32 accumulation, fp32 storage and every other op fp32): the reference trains under
+                  Trainer(precision='16-mixed') (scripts/main_train.py:110-123).  fp32 is the exact mode the gradient parity bar is on.
   chunk_slices    slices encoded per pass (activations of a pass sized for the Infinity Cache).
   full_attention_maps  keep the complete [n,h,N,N] softmax of every block on ``save_attn`` (needed
                   only by ``get_attention_cls``); default keeps the CLS rows ([n,h,1,N]) only.
@@ -209,6 +212,9 @@ class DinoV2ClassifierSlice(BasicClassifier):
         # tokens): measured on the MI355X box the 16 x 224^2 forward takes 1.083 ms eager and 1.082 ms replayed -- the ~90 launches are
         # not the bound, the under-filled kernels are (profiles/r04d_small_shapes.txt).  Results are the eager ones bit for bit.
         use_graph = str(kwargs.pop("use_graph", os.environ.get("MST_USE_GRAPH", "0"))).lower()
+        train_precision = str(kwargs.pop("train_precision", os.environ.get("MST_TRAIN_PRECISION", "fp32"))).lower()
+        if train_precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError("train_precision must be 'fp32', 'bf16' or 'fp16'")
         if compute_dtype not in hip.DT_NAMES:
             raise ValueError(f"compute_dtype must be one of {sorted(hip.DT_NAMES)}")
         super().__init__(in_ch, out_ch, spatial_dims=spatial_dims, optimizer_kwargs=optimizer_kwargs, **kwargs)
@@ -219,6 +225,7 @@ class DinoV2ClassifierSlice(BasicClassifier):
         self.full_attention_maps = full_attention_maps
         self.prune_last_block = prune_last_block
         self.use_graph = use_graph
+        self.train_precision = train_precision
         self._graphs = {}
         self.save_attn = save_attn
         self.attention_maps = []

@@ -24,13 +24,26 @@ from . import hip
 PATCH = 14
 
 
-def _lin_fwd(x: torch.Tensor, lin, **kw) -> torch.Tensor:
-    return hip.gemm(x, lin.weight.detach(), lin.bias.detach(), **kw)
+_MP = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def _mp(model) -> Optional[torch.dtype]:
+    """MFMA operand type of the per-slice encoder's nn.Linear products in the training step: None = exact fp32 MFMA (default),
+    bf16 / fp16 = mixed precision -- what the reference's Trainer(precision='16-mixed') (scripts/main_train.py:110-123) does to
+    F.linear: 16-bit operands, fp32 accumulation, fp32 everywhere else (LayerNorm, softmax, GELU, residuals, gradients in memory)."""
+    return _MP[getattr(model, "train_precision", "fp32")]
+
+
+def _lin_fwd(x: torch.Tensor, lin, mp: Optional[torch.dtype] = None, **kw) -> torch.Tensor:
+    if mp is None:
+        return hip.gemm(x, lin.weight.detach(), lin.bias.detach(), **kw)
+    return hip.gemm(hip.cvt16(x, mp), hip.cvt16(lin.weight.detach(), mp), lin.bias.detach(), out_dtype=torch.float32, **kw)
 
 
 class _Grads:
-    def __init__(self):
+    def __init__(self, mp: Optional[torch.dtype] = None):
         self.by_param: Dict[int, torch.Tensor] = {}
+        self.mp = mp
 
     def put(self, param, g: torch.Tensor):
         g = g.reshape(param.shape)
@@ -44,6 +57,8 @@ class _Grads:
         M, N = dY.shape
         K = X.shape[1]
         dev = dY.device
+        if self.mp is not None and N % 128 == 0 and K % 128 == 0:
+            return self._lin_bwd_16(dY, X, lin, need_dx)
         # d weight: an [N, K] output reduced over M rows is 36-144 tiles walking thousands of rows each; split the rows into up to
         # 16 slabs (more workgroups than CUs), partial products reduced by mst_colsum
         sp = next((d for d in (16, 8, 4, 2) if M % d == 0 and M // d >= 64), 1)
@@ -63,6 +78,26 @@ class _Grads:
         dX = torch.empty((M, K), dtype=torch.float32, device=dev)
         hip.gemm_ex(dY, lin.weight.detach(), dX, M, K, N, sa=(N, 1), sb=(K, 1), sc=(K, 1))
         return dX
+
+    def _lin_bwd_16(self, dY: torch.Tensor, X: torch.Tensor, lin, need_dx: bool) -> Optional[torch.Tensor]:
+        """The same three results on 16-bit MFMA operands (fp32 accumulation, fp32 results): operands are rounded into scratch images right
+        before each product -- d weight needs both of its operands contiguous along the token index, i.e. the TRANSPOSED images, and is
+        split over the tokens (mst_gemm16_splitk) so that its few output tiles fill the chip."""
+        M, N = dY.shape
+        K = X.shape[1]
+        dev = dY.device
+        mp = self.mp
+        tiles = (N // 128) * (K // 128)
+        sp = max(1, min(64, 512 // tiles))
+        kc = -(-M // (sp * 64)) * 64                                     # token rows per split, a multiple of the K-step
+        part = hip.gemm16_splitk(hip.cvt16(dY, mp, transpose=True, rows_pad=kc * sp), hip.cvt16(X, mp, transpose=True, rows_pad=kc * sp), sp)
+        self.put(lin.weight, hip.colsum(part.view(sp, N * K), torch.zeros(N * K, dtype=torch.float32, device=dev)).view(N, K))
+        if getattr(lin, "bias", None) is not None:
+            self.put(lin.bias, hip.colsum(dY, torch.zeros(N, dtype=torch.float32, device=dev)))
+        if not need_dx:
+            return None
+        # dX = dY . W: W^T [K, N] plays nn.Linear's weight
+        return hip.gemm(hip.cvt16(dY, mp), hip.cvt16(lin.weight.detach(), mp, transpose=True), None, out_dtype=torch.float32)
 
     def ln_bwd(self, x, x_stride, ln, dy, dy_stride, dres, dres_stride, dx, dx_stride, rows, cols, eps):
         dev = dy.device
@@ -213,19 +248,20 @@ def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], wit
     xt = hip.patch_embed(vol, wsum, enc.patch_embed.proj.bias.detach(), prefix, pos_patch).view(M, E)
     # ---- blocks (block.py:89-114)
     blocks = []
+    mp = _mp(model)
     for blk in enc.block_list():
         s = {"x0": xt}
         s["xn1"] = hip.layernorm(xt, blk.norm1.weight.detach(), blk.norm1.bias.detach(), 1e-6)
-        s["qkv"] = _lin_fwd(s["xn1"], blk.attn.qkv, col_scale=0.125, scale_cols=E)            # q * head_dim^-0.5 (attention.py:60)
+        s["qkv"] = _lin_fwd(s["xn1"], blk.attn.qkv, mp, col_scale=0.125, scale_cols=E)            # q * head_dim^-0.5 (attention.py:60)
         s["a"], s["P"] = _attention_fwd(s["qkv"], n, N, heads, 64, 1.0, None)
-        s["br1"] = _lin_fwd(s["a"], blk.attn.proj)
+        s["br1"] = _lin_fwd(s["a"], blk.attn.proj, mp)
         x1 = xt.clone()
         hip.axpby_cols(s["br1"], x1, g=blk.ls1.gamma.detach() if hasattr(blk, "ls1") else None)
         s["x1"] = x1
         s["xn2"] = hip.layernorm(x1, blk.norm2.weight.detach(), blk.norm2.bias.detach(), 1e-6)
-        s["hpre"] = _lin_fwd(s["xn2"], blk.mlp.fc1)
+        s["hpre"] = _lin_fwd(s["xn2"], blk.mlp.fc1, mp)
         s["hact"] = hip.act_fwd(s["hpre"], 0)
-        s["br2"] = _lin_fwd(s["hact"], blk.mlp.fc2)
+        s["br2"] = _lin_fwd(s["hact"], blk.mlp.fc2, mp)
         x2 = x1.clone()
         hip.axpby_cols(s["br2"], x2, g=blk.ls2.gamma.detach() if hasattr(blk, "ls2") else None)
         blocks.append(s)
@@ -287,6 +323,7 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
     if not any(p.requires_grad for p in enc.parameters()):
         return G.by_param                                                        # frozen encoder (dino.py:65-67)
     # ---- encoder
+    G.mp = _mp(model)                                    # the blocks' nn.Linear products on 16-bit operands, if asked for
     E, heads = enc.embed_dim, enc.num_heads
     n = B * D
     gh, gw = H // PATCH, W // PATCH

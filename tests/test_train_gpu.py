@@ -139,6 +139,61 @@ def test_strided_batched_gemm_every_staging_mode(M, N, K, a_layout, b_layout):
         assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_operand_images_and_split_k_product(dt):
+    """mst_cvt16 (row-major and transposed, zero-padded images) is torch's round-to-nearest cast bit for bit, and mst_gemm16_splitk's
+    partial products sum to dY^T . X of the rounded operands (the d weight product of the mixed-precision step)."""
+    from mst import hip
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1000, 256, 384
+    dY, X = torch.randn(M, N, generator=g) * 1e-3, torch.randn(M, K, generator=g)
+    a = hip.cvt16(dY.cuda(), tdt)
+    assert a.dtype == tdt and torch.equal(a.cpu(), dY.to(tdt))
+    assert torch.equal(hip.cvt16(X.cuda(), tdt, scale=0.5).cpu(), (X * 0.5).to(tdt))
+    sp, kc = 4, 256
+    at = hip.cvt16(dY.cuda(), tdt, transpose=True, rows_pad=sp * kc)
+    xt = hip.cvt16(X.cuda(), tdt, transpose=True, rows_pad=sp * kc)
+    assert at.shape == (N, sp * kc) and torch.equal(at[:, :M].cpu(), dY.to(tdt).t()) and not at[:, M:].any()
+    part = hip.gemm16_splitk(at, xt, sp)
+    assert part.shape == (sp, N, K)
+    want = dY.to(tdt).double().t() @ X.to(tdt).double()
+    assert rel_l2(part.sum(0).cpu(), want) < 1e-5
+    with pytest.raises(RuntimeError, match="split"):
+        hip.gemm16_splitk(at, xt, 3)
+
+
+@pytest.mark.parametrize("prec,bar,gbar", [("fp16", 1e-2, 8e-3), ("bf16", 1.3e-1, 7e-2)])
+def test_mixed_precision_step_gradients_against_the_fp32_step(prec, bar, gbar):
+    """train_precision = fp16 / bf16 (the reference's Trainer(precision='16-mixed'), scripts/main_train.py:110-123): the blocks' nn.Linear
+    products on 16-bit MFMA operands, everything else as in the fp32 step.  Every parameter gradient against the fp32 step (which the
+    oracle pins at 1e-3), relative L2 norm per parameter <= bar and over all parameters together <= gbar: 2x the worst measured at this
+    shape (fp16 4.3e-3 / 3.6e-3, bf16 6.3e-2 / 3.5e-2; the max-norm of single parameters is not used: under bf16 a ReLU of the across-slice
+    layer's feed-forward flips on the perturbed embeddings and moves one entry of linear1's gradient by 27 %)."""
+    from mst.models import DinoV2ClassifierSlice
+    shape = (1, 1, 4, 224, 224)
+    src = synth.synth_volume(shape, 3).cuda()
+    tgt = torch.tensor([1]).cuda()
+
+    def grads(p):
+        m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, train_precision=p)
+        m.load_state_dict(synth.synth_state_dict("s", 0))
+        m = m.cuda().train()
+        logits = m(src)
+        torch.nn.functional.cross_entropy(logits, tgt).backward()
+        return logits.detach(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+    l32, g32 = grads("fp32")
+    l16, g16 = grads(prec)
+    assert set(g16) == set(g32)
+    assert float((l16 - l32).abs().max()) < bar
+    worst = max(float((g16[k] - g32[k]).norm() / g32[k].norm().clamp_min(1e-30)) for k in g32)
+    assert worst < bar, worst
+    glob = (sum(float((g16[k] - g32[k]).square().sum()) for k in g32) / sum(float(g32[k].square().sum()) for k in g32)) ** 0.5
+    assert glob < gbar, glob
+    with pytest.raises(ValueError):
+        DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, train_precision="fp8")
+
+
 def test_features_path_frozen_encoder_and_an_optimizer_step():
     g = load_golden("b2_mask")
     src = synth.synth_volume(tuple(int(v) for v in g["shape"]), int(g["seed"]) + 100)

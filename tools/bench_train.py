@@ -50,12 +50,13 @@ def train_case(name, model, shape, n=5):
 
 
 def main():
-    dino_shapes = ((1, 1, 16, 224, 224),) if "--only-dino-c1" in sys.argv else ((1, 1, 16, 224, 224), (2, 1, 32, 224, 224))
+    dino_shapes = ((1, 1, 16, 224, 224),) if "--only-dino-c1" in sys.argv else ((2, 1, 32, 224, 224),) if "--only-dino-2x32" in sys.argv else ((1, 1, 16, 224, 224), (2, 1, 32, 224, 224))
     for shape in (() if "--only-resnet" in sys.argv else dino_shapes):
-        m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False)
-        m.load_state_dict(synth.synth_state_dict("s", 0))
-        train_case("DinoV2ClassifierSlice training step (fp32 HIP backward)", m, shape)
-    if "--only-dino-c1" in sys.argv:
+        for prec in (("fp32", "bf16", "fp16") if "--mixed" in sys.argv else ("fp16",) if "--fp16" in sys.argv else ("fp32",)):
+            m = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, train_precision=prec)
+            m.load_state_dict(synth.synth_state_dict("s", 0))
+            train_case(f"DinoV2ClassifierSlice training step ({prec} linear products, HIP backward)", m, shape)
+    if "--only-dino-c1" in sys.argv or "--only-dino-2x32" in sys.argv:
         return
     for shape in ((2, 1, 32, 224, 224),):
         m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
