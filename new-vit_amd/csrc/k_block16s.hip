@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void block16s_kernel(float* x, const T* attn, 
                 lds_read_b128_acc<64>(bt2, baddr);
                 lds_read_b128_acc<96>(bt3, baddr);
             }
-#ifdef BLOCKS_WAIT2
+#ifndef BLOCKS_WAIT1                                       // default since r04j: -1 % kernel time (1.074 -> 1.062 ms in the bench pipeline)
             // ONE counted wait per two slots: at an even slot fragments i and i + 1 have landed once only the reads behind
             // fragment i + 1 are outstanding (fragments i + 2 .. last issued, plus the four b1 reads where they are younger)
             if constexpr (i % 2 == 0) {
