@@ -8,11 +8,12 @@ import torch
 from mst import synth
 from mst.models import DinoV2ClassifierSlice
 
-for mode in ("bf16", "fp32"):
+only = "--bf16-16-only" in sys.argv                # profiling: one mode, one shape, no graph
+for mode in (("bf16",) if only else ("bf16", "fp32")):
     model = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, compute_dtype=mode)
     model.load_state_dict(synth.synth_state_dict("s", 0))
     model = model.cuda().eval()
-    for shape in ((1, 1, 16, 224, 224), (1, 1, 32, 224, 224)):
+    for shape in (((1, 1, 16, 224, 224),) if only else ((1, 1, 16, 224, 224), (1, 1, 32, 224, 224))):
         src = torch.randn(*shape, device="cuda")
         with torch.no_grad():
             for _ in range(5):
@@ -24,6 +25,9 @@ for mode in ("bf16", "fp32"):
                 out = model(src)
             torch.cuda.synchronize()
             eager = (time.perf_counter() - t0) / n
+            if only:
+                print({"mode": mode, "shape": shape, "eager_ms": round(eager * 1e3, 3)})
+                continue
             g = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
