@@ -142,6 +142,13 @@ int mst_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int kw, 
  * by MST_EPI_RESIDUAL / _RESIDUAL_RELU); epilogue MST_EPI_BIAS / MST_EPI_BIAS_RELU / MST_EPI_RESIDUAL / MST_EPI_RESIDUAL_RELU. */
 int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, const float* bias,
                   float* out, int Cout, int Kpad, int epilogue, const float* gamma, mst_stream_t stream);
+/* mst_conv_gemm16: the implicit-GEMM convolution on 16-bit MFMA operands (fp32 accumulation): x [n,H,W,Cin] and Wg [Cout, kh*kw*Cin] bf16 / f16
+ * (Cin % 64 == 0, Cout % 4 == 0), out [n*Ho*Wo, Cout] of out_dtype: MST_EPI_BIAS / MST_EPI_BIAS_RELU -> the operand type or f32;
+ * MST_EPI_RESIDUAL_RELU -> out = relu(out + conv + bias) in place on a 16-bit out (the residual unit's exit).  The 16-bit inference path of
+ * the ResNet backbone (ResNet(..., compute_dtype='bf16')).  mst_cvt32: out[i] = float(x[i]), n % 4 == 0. */
+int mst_conv_gemm16(const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
+                    void* out, int out_dtype, int Cout, int epilogue, mst_stream_t stream);
+int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);
 int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream);
 /* Training step of the backbone (BASELINE configs[3]; what torch.autograd + nn.BatchNorm2d(train) do for the reference):

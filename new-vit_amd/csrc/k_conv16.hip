@@ -1,0 +1,204 @@
+// Implicit-GEMM convolution on 16-bit MFMA operands (bf16 / fp16 activations NHWC, fp32 accumulate): the 16-bit inference path of the
+// ResNet backbone (reference mst/models/resnet.py:44-50,172-193 over torchvision's resnet: F.conv2d + folded BatchNorm +
+// ReLU / residual).  The structure is k_gemm16.hip's (128 x BN x 64 tile, 4 waves 2 x 2, LDS-DMA double buffer, swizzle on the per-lane
+// SOURCE address), with the A operand GATHERED: row m = output pixel (img, oy, ox), a 64-wide K-step = 64 consecutive input channels of
+// ONE filter tap (Cin % 64 == 0), so every 1 KiB LDS-DMA piece is eight 128-byte runs of eight input pixels -- or of a zero page for
+// taps outside the image and rows beyond M (LDS-DMA has no predicated zero fill; the page is 128 bytes of zeros in device memory).
+// No [rows, kh*kw*Cin] matrix exists.  BN = 64 serves the 64-channel stage (and the stem's im2col product) without wasted MFMAs.
+//   epilogues: bias | bias + ReLU (16-bit or fp32 out) | relu(C + acc + bias) in place on a 16-bit C (the unit's exit).
+#include <type_traits>
+
+#include "mst_common.h"
+
+namespace {
+
+constexpr int BM = 128, BK = 64;
+__device__ __attribute__((aligned(128))) char conv16_zero_page[128];      // zero-initialised device memory
+
+struct Conv16Geom { int H, W, C, kh, kw, stride, pad, Ho, Wo; };
+
+template <typename T, int BN, int EPI, typename OutT>
+__global__ __launch_bounds__(256) void conv16_kernel(const T* __restrict__ x, Conv16Geom g, const T* __restrict__ Wg, int64_t ldw,
+                                                     const float* __restrict__ bias, OutT* C, int64_t ldc, int M, int N, int tiles_n, int nwg) {
+    typedef typename V8<T>::type vec8;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;       // per stage
+    constexpr int NI = BN / 32;                                       // 16-column accumulator blocks per wave (wave tile 64 x BN/2)
+    constexpr int PW = BN / 32;                                       // W pieces per wave and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const As = smem;                                            // [2][128][64] T
+    char* const Ws = smem + 2 * A_BYTES;                              // [2][BN][64] T
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- A pieces: instruction i of this wave fills tile rows (wave*4+i)*8 .. +7; lane -> row r, 16-byte chunk c of the 128-byte run
+    int py[4], px[4];                                                 // top-left input pixel of the row's window (may be negative)
+    int64_t pbase[4];                                                 // element offset of image `img` + this lane's chunk
+    const int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);                    // chunk whose swizzled home is LDS slot lane&7
+        const int m = m0 + r;
+        const int mm = m < M ? m : 0;
+        const int img = mm / hw, rem = mm - img * hw;
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        py[i] = m < M ? oy * g.stride - g.pad : -(1 << 20);           // rows beyond M: every tap out of range -> zero page
+        px[i] = ox * g.stride - g.pad;
+        pbase[i] = (int64_t)img * g.H * g.W * g.C + c * 8;
+    }
+    const T* wsrc[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int r = (wave * PW + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = n0 + r < N ? n0 + r : N - 1;
+        wsrc[i] = Wg + (int64_t)n * ldw + c * 8;
+    }
+    const char* const zsrc = conv16_zero_page + ((lane & 7) << 4);
+    const int cpk = g.C / BK;                                         // K-steps per filter tap
+    auto stage = [&](int t, int buf) {
+        const int tap = t / cpk, cc = (t - tap * cpk) * BK;           // scalar
+        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = py[i] + ky, ix = px[i] + kx;
+            const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const char* src = ok ? reinterpret_cast<const char*>(x + pbase[i] + ((int64_t)iy * g.W + ix) * g.C + cc) : zsrc;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(As + buf * A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i]), LDS_PTR(Ws + buf * W_BYTES + (wave * PW + i) * 1024), 16, 0, 0);
+            wsrc[i] += BK;
+        }
+    };
+
+    // accumulators start at the bias
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
+        if (bias && n < N) b0 = *reinterpret_cast<const f32x4*>(bias + n);                 // N % 4 == 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = b0;
+    }
+
+    const int sw = (lane >> 1) & 7;                                   // ((row >> 1) & 7) for row = 16*k + (lane & 15)
+    const int a_row_off = (wm * 64 + (lane & 15)) * 128;
+    const int w_row_off = (wn * (BN / 2) + (lane & 15)) * 128;
+
+    const int nk = g.kh * g.kw * cpk;
+    stage(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // tile t has landed; every wave is done reading the other buffer
+        if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+        const char* Ab = As + (t & 1) * A_BYTES;
+        const char* Wb = Ws + (t & 1) * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
+            vec8 af[4], wf[NI];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const vec8*>(Ab + a_row_off + j * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const vec8*>(Wb + w_row_off + i * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[i], af[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = m0+wm*64+j*16+(lane&15), n = n0+wn*(BN/2)+i*16+(lane>>4)*4
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+            if (m >= M) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            OutT* cp = C + (int64_t)m * ldc + n;
+            if constexpr (EPI == MST_EPI_RESIDUAL_RELU) {
+                typedef __attribute__((ext_vector_type(4))) OutT o4;
+                const o4 idv = *reinterpret_cast<const o4*>(cp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + (float)idv[r], 0.f);
+            } else if constexpr (EPI == MST_EPI_BIAS_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                typedef __attribute__((ext_vector_type(4))) OutT o4;
+                o4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (OutT)v[r];
+                *reinterpret_cast<o4*>(cp) = pk;
+            }
+        }
+    }
+}
+
+template <typename T, int BN, int EPI, typename OutT>
+int launch_k(const void* x, const Conv16Geom& g, int n, const void* Wg, int64_t ldw, const float* bias, void* C, int64_t ldc, int N,
+             hipStream_t s) {
+    static mst_lds_once lds_once;
+    auto kern = conv16_kernel<T, BN, EPI, OutT>;
+    constexpr int lds = 2 * BM * BK * 2 + 2 * BN * BK * 2;
+    mst_allow_lds((const void*)kern, lds, &lds_once);
+    const int64_t M = (int64_t)n * g.Ho * g.Wo;
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)x, g, (const T*)Wg, ldw, bias, (OutT*)C, ldc, (int)M, N, tiles_n, nwg);
+    return mst_check_launch("conv16");
+}
+
+template <typename T, int BN>
+int dispatch_epi(const void* x, const Conv16Geom& g, int n, const void* Wg, int64_t ldw, const float* bias, void* C, int cdt, int64_t ldc,
+                 int N, int epi, hipStream_t s) {
+    const bool f32out = cdt == MST_F32;
+    switch (epi) {
+        case MST_EPI_BIAS:
+            return f32out ? launch_k<T, BN, MST_EPI_BIAS, float>(x, g, n, Wg, ldw, bias, C, ldc, N, s)
+                          : launch_k<T, BN, MST_EPI_BIAS, T>(x, g, n, Wg, ldw, bias, C, ldc, N, s);
+        case MST_EPI_BIAS_RELU:
+            return f32out ? launch_k<T, BN, MST_EPI_BIAS_RELU, float>(x, g, n, Wg, ldw, bias, C, ldc, N, s)
+                          : launch_k<T, BN, MST_EPI_BIAS_RELU, T>(x, g, n, Wg, ldw, bias, C, ldc, N, s);
+        case MST_EPI_RESIDUAL_RELU:
+            if (!f32out) return launch_k<T, BN, MST_EPI_RESIDUAL_RELU, T>(x, g, n, Wg, ldw, bias, C, ldc, N, s);
+    }
+    mst_set_error("conv_gemm16: epilogue %d with output dtype %d unsupported (bias, bias + ReLU: 16-bit or f32 out; residual + ReLU: 16-bit in place)", epi, cdt);
+    return MST_EINVAL;
+}
+
+}  // namespace
+
+// out[(img, oy, ox)][co] = epi(sum_{ky,kx,c} x[img][oy*stride-pad+ky][ox*stride-pad+kx][c] * Wg[co][(ky,kx,c)] + bias[co]) on 16-bit MFMA
+// operands: x [n,H,W,Cin] and Wg [Cout, kh*kw*Cin] of type dt (Cin % 64 == 0, Cout % 4 == 0), out [n*Ho*Wo, Cout] of type cdt.
+int launch_conv_gemm16(const void* x, int dt, int n, int H, int W_, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
+                       void* out, int cdt, int Cout, int epi, hipStream_t s) {
+    MST_CHECK_ARG(x && Wg && out && n > 0 && H > 0 && W_ > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv_gemm16: bad arguments");
+    MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "conv_gemm16: operand dtype %d (bf16 / f16)", dt);
+    MST_CHECK_ARG(cdt == MST_F32 || cdt == dt, "conv_gemm16: output dtype must be f32 or the operand dtype");
+    MST_CHECK_ARG(Cin % BK == 0, "conv_gemm16: Cin=%d must be a multiple of %d", Cin, BK);
+    MST_CHECK_ARG(Cout > 0 && Cout % 4 == 0, "conv_gemm16: Cout=%d must be a multiple of 4", Cout);
+    MST_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)Wg & 15) == 0 && ((uintptr_t)out & 15) == 0, "conv_gemm16: bases must be 16-byte aligned");
+    Conv16Geom g{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1};
+    MST_CHECK_ARG(g.Ho > 0 && g.Wo > 0 && (int64_t)n * g.Ho * g.Wo < (1ll << 31) - BM, "conv_gemm16: output %d x %d x %d", n, g.Ho, g.Wo);
+    const int64_t ldw = (int64_t)kh * kw * Cin;
+    const bool narrow = Cout <= 64;
+    if (dt == MST_BF16)
+        return narrow ? dispatch_epi<bf16_t, 64>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s)
+                      : dispatch_epi<bf16_t, 128>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s);
+    return narrow ? dispatch_epi<f16_t, 64>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s)
+                  : dispatch_epi<f16_t, 128>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s);
+}

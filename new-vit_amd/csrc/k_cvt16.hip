@@ -47,7 +47,28 @@ __global__ __launch_bounds__(256) void cvt16_t_kernel(const float* __restrict__ 
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void cvt32_kernel(const T* __restrict__ x, int64_t n4, float* __restrict__ out) {
+    typedef __attribute__((ext_vector_type(4))) T i4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const i4 v = reinterpret_cast<const i4*>(x)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+
 }  // namespace
+
+// out[i] = float(x[i]) for n 16-bit values (n % 4 == 0): where an fp32 kernel reads what a 16-bit one wrote (the last activation of the
+// 16-bit ResNet backbone before the average pool and Grad-CAM++)
+int launch_cvt32(const void* x, int dt, int64_t n, float* out, hipStream_t s) {
+    MST_CHECK_ARG(x && out && n > 0 && n % 4 == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)out & 15) == 0, "cvt32: n=%lld must be a multiple of 4, bases aligned", (long long)n);
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (dt == MST_BF16) cvt32_kernel<bf16_t><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)x, n4, out);
+    else if (dt == MST_F16) cvt32_kernel<f16_t><<<dim3(grid), dim3(256), 0, s>>>((const f16_t*)x, n4, out);
+    else { mst_set_error("cvt32: input dtype %d (bf16 / f16)", dt); return MST_EINVAL; }
+    return mst_check_launch("cvt32");
+}
 
 int launch_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int dt, int64_t ldo, int transpose,
                  int64_t rows_pad, hipStream_t s) {

@@ -237,6 +237,11 @@ int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, 
                   float* out, int Cout, int Kpad, int epilogue, const float* gamma, mst_stream_t stream) {
     return launch_conv_gemm32(x, n, H, W, Cin, kh, kw, stride, pad, Wg, Kpad, bias, out, Cout, Cout, Kpad, epilogue, gamma, (hipStream_t)stream);
 }
+int mst_conv_gemm16(const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
+                    void* out, int out_dtype, int Cout, int epilogue, mst_stream_t stream) {
+    return launch_conv_gemm16(x, dtype, n, H, W, Cin, kh, kw, stride, pad, Wg, bias, out, out_dtype, Cout, epilogue, (hipStream_t)stream);
+}
+int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream) { return launch_cvt32(x, dtype, n, out, (hipStream_t)stream); }
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");
     return launch_maxpool_nhwc(x, n, H, W, C, y, (hipStream_t)stream);

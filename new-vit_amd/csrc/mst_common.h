@@ -170,6 +170,9 @@ int launch_gemm16_splitk(const void* A, int dt, int64_t lda, const void* W, int6
                          int splits, int64_t split_stride, hipStream_t s);
 int launch_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int dt, int64_t ldo, int transpose,
                  int64_t rows_pad, hipStream_t s);
+int launch_cvt32(const void* x, int dt, int64_t n, float* out, hipStream_t s);
+int launch_conv_gemm16(const void* x, int dt, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
+                       void* out, int cdt, int Cout, int epi, hipStream_t s);
 int launch_conv_gemm32(const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const float* Wg, int64_t ldw,
                        const float* bias, float* out, int64_t ldc, int Cout, int Kpad, int epi, const float* gamma, hipStream_t s);
 bool gemm32_small_applicable(int64_t M, int N, int K);

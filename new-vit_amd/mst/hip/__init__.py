@@ -85,6 +85,8 @@ SIGNATURES = {
     "mst_cvt16": (_i, [_vp, _i64, _i64, _i, _f, _vp, _i, _i64, _i, _i64, _vp]),
     "mst_gemm16_splitk": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i64, _vp]),
     "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_batchnorm_train": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -672,6 +674,33 @@ def conv_gemm(x: torch.Tensor, wg: torch.Tensor, bias: Optional[torch.Tensor], k
         out = torch.empty((n * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
     _check(load().mst_conv_gemm(ptr(x), n, H, W, Cin, kh, kw, stride, pad, ptr(wg), ptr(bias), ptr(out), Cout, kpad, epilogue, ptr(gamma),
                                 stream_of(x)), "mst_conv_gemm")
+    return out
+
+
+def conv_gemm16(x: torch.Tensor, wg: torch.Tensor, bias: Optional[torch.Tensor], kh: int, kw: int, stride: int, pad: int, *,
+                epilogue: int = EPI_BIAS, out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """mst_conv_gemm16: convolution of x [n,H,W,Cin] (NHWC bf16 / fp16, Cin % 64 == 0) with wg [Cout, kh*kw*Cin] of the same type as an
+    implicit GEMM on 16-bit MFMA operands -> [n*Ho*Wo, Cout] (the operand type, or fp32).  out: the 16-bit residual operand of
+    EPI_RESIDUAL_RELU (updated in place)."""
+    _dev(x, "conv_gemm16")
+    _dev(wg, "conv_gemm16")
+    n, H, W, Cin = x.shape
+    Cout = wg.shape[0]
+    if wg.shape[1] != kh * kw * Cin:
+        raise ValueError(f"conv_gemm16: weight [{Cout}, {wg.shape[1]}] does not match kh*kw*Cin = {kh * kw * Cin}")
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n * Ho * Wo, Cout), dtype=out_dtype or x.dtype, device=x.device)
+    _check(load().mst_conv_gemm16(ptr(x), dt_of(x), n, H, W, Cin, kh, kw, stride, pad, ptr(wg), ptr(bias), ptr(out), dt_of(out), Cout, epilogue,
+                                  stream_of(x)), "mst_conv_gemm16")
+    return out
+
+
+def cvt32(x: torch.Tensor) -> torch.Tensor:
+    """mst_cvt32: fp32 copy of a 16-bit tensor."""
+    _dev(x, "cvt32")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _check(load().mst_cvt32(ptr(x), dt_of(x), x.numel(), ptr(out), stream_of(x)), "mst_cvt32")
     return out
 
 

@@ -129,6 +129,8 @@ def _conv(x: torch.Tensor, w: torch.Tensor, b, k: int, stride: int, pad: int, kp
     """One convolution of the backbone on an NHWC activation -> [n*Ho*Wo, Cout]: the implicit GEMM (mst_conv_gemm) when the input
     channels allow it (Cin % 16 == 0: every layer behind the stem) and there are more than 1,024 output pixels, else im2col + GEMM.  MST_CONV_IM2COL=1 forces the latter (A/B)."""
     n, H, W, cin = x.shape
+    if x.dtype != torch.float32:                         # compute_dtype bf16 / fp16: the implicit GEMM on 16-bit MFMA operands (Cin % 64 == 0)
+        return hip.conv_gemm16(x, w, b, k, k, stride, pad, epilogue=epilogue, out=out)
     rows = n * ((H + 2 * pad - k) // stride + 1) * ((W + 2 * pad - k) // stride + 1)
     # up to 1,024 output pixels mst_gemm has its 32 x 32-tile kernel (k_gemm32s.hip), which fills the chip where 128 x 128 tiles cannot
     if cin % 16 == 0 and rows > 1024 and os.environ.get("MST_CONV_IM2COL", "0") != "1":
@@ -136,8 +138,9 @@ def _conv(x: torch.Tensor, w: torch.Tensor, b, k: int, stride: int, pad: int, kp
     return hip.gemm(hip.im2col_nhwc(x, k, k, stride, pad, kpad), w, b, epilogue=epilogue, out=out)
 
 
-def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev):
-    """Eval-mode BatchNorm folded into the convolution: GEMM weight [Cout, Kpad] in (ky, kx, c) order + bias [Cout]."""
+def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev, dtype: torch.dtype = torch.float32, kmul: int = 16):
+    """Eval-mode BatchNorm folded into the convolution: GEMM weight [Cout, Kpad] in (ky, kx, c) order (fp32, or rounded to the 16-bit
+    compute type AFTER the fold) + bias [Cout] fp32; K padded to a multiple of kmul."""
     w = conv.weight.detach().to(dev, torch.float32)
     if sum_in:
         w = w.sum(dim=1, keepdim=True)                   # identical input channels (gray -> RGB repeat): one summed kernel
@@ -145,10 +148,10 @@ def _fold(conv: _Conv, bn: _BN, sum_in: bool, dev):
     b = bn.bias.detach().to(dev, torch.float32) - bn.running_mean.to(dev, torch.float32) * s
     w = (w * s[:, None, None, None]).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     K = w.shape[1]
-    kpad = (K + 15) // 16 * 16
+    kpad = (K + kmul - 1) // kmul * kmul
     if kpad != K:
         w = torch.cat([w, w.new_zeros(w.shape[0], kpad - K)], dim=1)
-    return w.contiguous(), b.contiguous(), kpad
+    return w.to(dtype).contiguous(), b.contiguous(), kpad
 
 
 class ResNet(BasicClassifier):
@@ -156,6 +159,13 @@ class ResNet(BasicClassifier):
         emb_ch = kwargs.pop("emb_ch", out_ch)
         self.chunk_images = int(kwargs.pop("chunk_images", 128))      # build-specific: images per backbone pass (activation memory:
         #                                                               0.4 GB for the stem's output at 128 images of 224 x 224)
+        # build-specific: MFMA operand / activation type of the INFERENCE backbone: 'fp32' (default, exact: the parity mode) | 'bf16' | 'fp16'
+        # (16-bit NHWC activations behind the stem's max pool, fp32 accumulation, folded BatchNorm bias in fp32; the slice transformer and
+        # the head stay fp32).  The training step is fp32 whatever this says.
+        cdt = str(kwargs.pop("compute_dtype", os.environ.get("MST_RESNET_DTYPE", "fp32"))).lower()
+        if cdt not in ("fp32", "bf16", "fp16"):
+            raise ValueError("ResNet: compute_dtype must be 'fp32', 'bf16' or 'fp16'")
+        self.compute_dtype_name = cdt
         super().__init__(in_ch, out_ch, spatial_dims, **kwargs)
         self.attention_maps = []
         if spatial_dims != 2:
@@ -197,21 +207,23 @@ class ResNet(BasicClassifier):
         return v
 
     def _prepare(self, sum_in: bool):
-        key = (sum_in, str(self.device), self._state_version())
+        cdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[self.compute_dtype_name]
+        key = (sum_in, str(self.device), self._state_version(), self.compute_dtype_name)
         if self._prep is not None and self._prep["key"] == key:
             return self._prep
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError(f"ResNet runs on an MI355X only: parameters are on {dev}; call .to('cuda'). There is no CPU fallback.")
         m = self.model
-        prep = {"key": key, "stem": _fold(m.conv1, m.bn1, sum_in, dev), "blocks": []}
+        # 16-bit: the stem's im2col rows are padded to 64 columns so that they are one "pixel" of a 1 x 1 convolution for mst_conv_gemm16
+        prep = {"key": key, "dtype": cdt, "stem": _fold(m.conv1, m.bn1, sum_in, dev, cdt, 16 if cdt == torch.float32 else 64), "blocks": []}
         for li in range(4):
             for blk in getattr(m, f"layer{li + 1}"):
-                e = {"stride": blk.stride, "c1": _fold(blk.conv1, blk.bn1, False, dev), "c2": _fold(blk.conv2, blk.bn2, False, dev)}
+                e = {"stride": blk.stride, "c1": _fold(blk.conv1, blk.bn1, False, dev, cdt), "c2": _fold(blk.conv2, blk.bn2, False, dev, cdt)}
                 if hasattr(blk, "conv3"):
-                    e["c3"] = _fold(blk.conv3, blk.bn3, False, dev)
+                    e["c3"] = _fold(blk.conv3, blk.bn3, False, dev, cdt)
                 if hasattr(blk, "downsample"):
-                    e["ds"] = _fold(blk.downsample[0], blk.downsample[1], False, dev)
+                    e["ds"] = _fold(blk.downsample[0], blk.downsample[1], False, dev, cdt)
                 prep["blocks"].append(e)
         if not isinstance(m.fc, nn.Identity):
             prep["fc"] = (m.fc.weight.detach().to(dev, torch.float32).contiguous(), m.fc.bias.detach().to(dev, torch.float32).contiguous())
@@ -229,8 +241,17 @@ class ResNet(BasicClassifier):
             n, H, W, _ = x.shape
             w, b, kpad = p["stem"]
             Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-            y = hip.gemm(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), w, b, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, 64)
-            y = hip.maxpool_nhwc(y)
+            if p["dtype"] == torch.float32:
+                y = hip.gemm(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), w, b, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, 64)
+                y = hip.maxpool_nhwc(y)
+            else:
+                # the stem's 49 taps of ONE input channel are no multiple of 64 channels: its im2col rows (padded to 64) are the "pixels" of a
+                # 1 x 1 convolution; the max pool stays fp32, the activations behind it are 16-bit
+                col = hip.cvt16(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), p["dtype"]).view(n, Ho, Wo, kpad)
+                y = hip.conv_gemm16(col, w, b, 1, 1, 1, 0, epilogue=hip.EPI_BIAS_RELU, out_dtype=torch.float32).view(n, Ho, Wo, 64)
+                del col
+                y = hip.maxpool_nhwc(y)
+                y = hip.cvt16(y.view(-1, 64), p["dtype"]).view(y.shape)
             for e in p["blocks"]:
                 n, H, W, Cin = y.shape
                 s = e["stride"]
@@ -258,6 +279,8 @@ class ResNet(BasicClassifier):
                 w2, b2, k2 = e["c2"]
                 _conv(x=h1, w=w2, b=b2, k=3, stride=1, pad=1, kpad=k2, epilogue=hip.EPI_RESIDUAL_RELU, out=idt)  # relu(identity + bn2(conv2(.)))
                 y = idt.view(n, Ho, Wo, w2.shape[0])
+            if y.dtype != torch.float32:
+                y = hip.cvt32(y)                         # the average pool and Grad-CAM++ read fp32
             outs.append(hip.avgpool_nhwc(y))
             if keep_last:
                 lasts.append(y)

@@ -309,6 +309,65 @@ def test_implicit_gemm_convolution_equals_im2col_gemm_and_torch(n, cin, cout, k,
     assert rel_l2(got.cpu(), want) < 1e-5
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw,epi,f32out", [
+    (3, 64, 64, 3, 1, 1, (16, 15), "relu", False), (2, 64, 128, 3, 2, 1, (41, 37), "bias", False), (5, 128, 256, 1, 2, 0, (35, 27), "bias", True),
+    (2, 64, 200, 3, 1, 1, (9, 7), "relu", True), (1, 256, 64, 1, 1, 0, (3, 3), "residual_relu", False), (2, 128, 128, 3, 1, 1, (20, 13), "residual_relu", False),
+    (7, 512, 512, 3, 1, 1, (2, 2), "relu", False), (2, 192, 64, 1, 1, 0, (30, 30), "relu", True)])
+def test_implicit_gemm_convolution_on_16_bit_operands(dt, n, cin, cout, k, stride, pad, hw, epi, f32out):
+    """mst_conv_gemm16 (the 16-bit inference path of the backbone): gathered A operand with a zero page for padding taps and rows beyond M,
+    64- and 128-column tiles, partial column tiles, every epilogue and output type, against fp64 conv2d of the SAME rounded operands."""
+    import torch.nn.functional as F
+    from mst import hip
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + k)
+    x = torch.randn(n, cin, *hw, generator=g).to(tdt)
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(tdt)
+    b = torch.randn(cout, generator=g)
+    Ho, Wo = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
+    res = torch.randn(n * Ho * Wo, cout, generator=g).to(tdt)
+    e = {"bias": hip.EPI_BIAS, "relu": hip.EPI_BIAS_RELU, "residual_relu": hip.EPI_RESIDUAL_RELU}[epi]
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wh = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    out = res.cuda().clone() if epi == "residual_relu" else None
+    got = hip.conv_gemm16(xh, wh, b.cuda(), k, k, stride, pad, epilogue=e, out=out, out_dtype=torch.float32 if f32out else None)
+    assert got.shape == (n * Ho * Wo, cout) and got.dtype == (torch.float32 if f32out else tdt)
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(-1, cout)
+    want = F.relu(want) if epi == "relu" else F.relu(want + res.double()) if epi == "residual_relu" else want
+    tol = 1e-5 if f32out else {"bf16": 4e-3, "fp16": 5e-4}[dt]                      # 16-bit outputs: one rounding of the result
+    assert rel_l2(got.float().cpu(), want) < tol
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        hip.conv_gemm16(torch.zeros(1, 4, 4, 32, dtype=tdt, device="cuda"), torch.zeros(8, 32, dtype=tdt, device="cuda"), None, 1, 1, 1, 0)
+
+
+@pytest.mark.parametrize("cdt,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+@pytest.mark.parametrize("model", [34, 50])
+def test_16_bit_inference_backbone_against_the_fp32_one(cdt, tol, model):
+    """ResNetSliceTrans(compute_dtype=bf16 / fp16): 16-bit NHWC activations and MFMA operands in the backbone (fp32 accumulation, folded
+    BatchNorm bias, pooling, slice transformer and head in fp32) against the exact fp32 path of the same weights: slice embeddings and
+    logits within the stated 16-bit bars (measured: see profiles/r04l_resnet_16bit.txt), Grad-CAM++ maps produced and finite."""
+    import warnings
+    from mst.models import ResNetSliceTrans
+    sd = synth.synth_resnet_state_dict(5, model, 2)
+    src = synth.synth_volume((2, 1, 5, 96, 80), 6).cuda()
+    outs = {}
+    for c in ("fp32", cdt):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=model, compute_dtype=c)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            logits = m(src, save_attn=True)
+            emb = m._features(src.float().reshape(10, 96, 80, 1).contiguous(), True)
+        outs[c] = (logits.float().cpu(), emb.cpu(), m.get_attention_maps().cpu())
+    assert rel_l2(outs[cdt][1], outs["fp32"][1]) < tol
+    assert float((outs[cdt][0] - outs["fp32"][0]).abs().max()) < tol * max(1.0, float(outs["fp32"][0].abs().max()))
+    assert torch.isfinite(outs[cdt][2]).all() and outs[cdt][2].shape == outs["fp32"][2].shape
+    with pytest.raises(ValueError):
+        ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8")
+
+
 def test_implicit_gemm_convolution_rejects_what_it_cannot_gather():
     from mst import hip
     x = torch.zeros(1, 4, 4, 3, device="cuda")

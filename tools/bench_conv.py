@@ -61,6 +61,19 @@ def model():
             t = timeit(lambda: m(src), it=5)
         print(f"ResNetSliceTrans(34) forward [4,1,32,224,224]  MST_CONV_IM2COL={mode}: {t:.2f} ms  peak {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
         torch.cuda.reset_peak_memory_stats()
+    os.environ["MST_CONV_IM2COL"] = "0"
+    ref = None
+    for shape in ((4, 1, 32, 224, 224), (1, 1, 128, 512, 512)):
+        src = torch.randn(*shape, device="cuda")
+        for cdt in ("fp32", "bf16", "fp16"):
+            m.compute_dtype_name = cdt
+            with torch.no_grad():
+                out = m(src)
+                t = timeit(lambda: m(src), it=5)
+            ref = out if cdt == "fp32" else ref
+            print(f"ResNetSliceTrans(34) forward {list(shape)} compute_dtype={cdt}: {t:.2f} ms  peak {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB  "
+                  f"max |dlogits| vs fp32 {float((out - ref).abs().max()):.2e}")
+            torch.cuda.reset_peak_memory_stats()
 
 
 if __name__ == "__main__":
