@@ -149,6 +149,12 @@ int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, 
 int mst_conv_gemm16(const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
                     void* out, int out_dtype, int Cout, int epilogue, mst_stream_t stream);
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream);
+/* mst_conv_dgrad: d input of a convolution AS a convolution (what torch.autograd's conv backward gives the reference): the same implicit GEMMs
+ * with stride 1, padding k - 1 - pad and the gradient rows dilated by the forward stride (1 or 2), instead of dZ . W into a [rows, kh*kw*Cin]
+ * matrix and a scatter with atomics (mst_col2im_nhwc).  dz [n,Ho,Wo,Cout] and Wt [Cin, kh*kw*Cout] of `dtype` (f32: Cout % 16 == 0; bf16 / f16:
+ * Cout % 64 == 0), Wt[c][(ky',kx',co)] = W[co][c][k-1-ky'][k-1-kx']; dx fp32 [n*H*W, Cin], overwritten. */
+int mst_conv_dgrad(const void* dz, int dtype, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W,
+                   int Cin, float* dx, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);
 int mst_avgpool_nhwc(const float* x, int n, int HW, int C, float* y, mst_stream_t stream);
 /* Training step of the backbone (BASELINE configs[3]; what torch.autograd + nn.BatchNorm2d(train) do for the reference):

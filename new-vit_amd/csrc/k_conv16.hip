@@ -15,7 +15,7 @@ namespace {
 constexpr int BM = 128, BK = 64;
 __device__ __attribute__((aligned(128))) char conv16_zero_page[128];      // zero-initialised device memory
 
-struct Conv16Geom { int H, W, C, kh, kw, stride, pad, Ho, Wo; };
+struct Conv16Geom { int H, W, C, kh, kw, stride, pad, Ho, Wo, dshift; };   // dshift: log2 of the input dilation (d input of a stride-2 layer: 1)
 
 template <typename T, int BN, int EPI, typename OutT>
 __global__ __launch_bounds__(256) void conv16_kernel(const T* __restrict__ x, Conv16Geom g, const T* __restrict__ Wg, int64_t ldw,
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const T* __restrict__ x, Co
         const int ky = tap / g.kw, kx = tap - ky * g.kw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int iy = py[i] + ky, ix = px[i] + kx;
-            const bool ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const int ny = py[i] + ky, nx = px[i] + kx, dmask = (1 << g.dshift) - 1;
+            const int iy = ny >> g.dshift, ix = nx >> g.dshift;
+            const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & dmask) == 0 && iy < g.H && ix < g.W;
             const char* src = ok ? reinterpret_cast<const char*>(x + pbase[i] + ((int64_t)iy * g.W + ix) * g.C + cc) : zsrc;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(As + buf * A_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
         }
@@ -192,7 +193,7 @@ int launch_conv_gemm16(const void* x, int dt, int n, int H, int W_, int Cin, int
     MST_CHECK_ARG(Cin % BK == 0, "conv_gemm16: Cin=%d must be a multiple of %d", Cin, BK);
     MST_CHECK_ARG(Cout > 0 && Cout % 4 == 0, "conv_gemm16: Cout=%d must be a multiple of 4", Cout);
     MST_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)Wg & 15) == 0 && ((uintptr_t)out & 15) == 0, "conv_gemm16: bases must be 16-byte aligned");
-    Conv16Geom g{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1};
+    Conv16Geom g{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1, 0};
     MST_CHECK_ARG(g.Ho > 0 && g.Wo > 0 && (int64_t)n * g.Ho * g.Wo < (1ll << 31) - BM, "conv_gemm16: output %d x %d x %d", n, g.Ho, g.Wo);
     const int64_t ldw = (int64_t)kh * kw * Cin;
     const bool narrow = Cout <= 64;
@@ -201,4 +202,25 @@ int launch_conv_gemm16(const void* x, int dt, int n, int H, int W_, int Cin, int
                       : dispatch_epi<bf16_t, 128>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s);
     return narrow ? dispatch_epi<f16_t, 64>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s)
                   : dispatch_epi<f16_t, 128>(x, g, n, Wg, ldw, bias, out, cdt, Cout, Cout, epi, s);
+}
+
+// d input of a convolution on 16-bit operands (see launch_conv_dgrad32): dz [n,Ho,Wo,Cout] and Wt [Cin, kh*kw*Cout] of type dt (Cout % 64 == 0),
+// dx [n*H*W, Cin] fp32, overwritten.
+int launch_conv_dgrad16(const void* dz, int dt, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W_,
+                        int Cin, float* dx, hipStream_t s) {
+    MST_CHECK_ARG(dz && Wt && dx && n > 0 && Ho > 0 && Wo > 0 && H > 0 && W_ > 0 && kh == kw && kh > 0 && pad >= 0 && pad < kh, "conv_dgrad16: bad arguments");
+    MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "conv_dgrad16: operand dtype %d (bf16 / f16)", dt);
+    MST_CHECK_ARG(stride == 1 || stride == 2, "conv_dgrad16: stride %d (1 or 2)", stride);
+    MST_CHECK_ARG(Cout % BK == 0 && Cin % 4 == 0, "conv_dgrad16: Cout=%d must be a multiple of %d, Cin=%d of 4", Cout, BK, Cin);
+    MST_CHECK_ARG((H + 2 * pad - kh) / stride + 1 == Ho && (W_ + 2 * pad - kw) / stride + 1 == Wo, "conv_dgrad16: %d x %d is not the output of a %d x %d input", Ho, Wo, H, W_);
+    MST_CHECK_ARG((int64_t)n * H * W_ < (1ll << 31) - BM, "conv_dgrad16: %d x %d x %d", n, H, W_);
+    MST_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)Wt & 15) == 0 && ((uintptr_t)dx & 15) == 0, "conv_dgrad16: bases must be 16-byte aligned");
+    Conv16Geom g{Ho, Wo, Cout, kh, kw, 1, kh - 1 - pad, H, W_, stride - 1};
+    const int64_t ldw = (int64_t)kh * kw * Cout;
+    const bool narrow = Cin <= 64;
+    if (dt == MST_BF16)
+        return narrow ? launch_k<bf16_t, 64, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s)
+                      : launch_k<bf16_t, 128, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s);
+    return narrow ? launch_k<f16_t, 64, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s)
+                  : launch_k<f16_t, 128, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s);
 }

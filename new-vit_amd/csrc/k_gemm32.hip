@@ -21,7 +21,7 @@ constexpr int BM = 128, BN = 128, BK = 16, LDP = 17;
 // column k = (ky, kx, c) with c fastest -- what mst_im2col_nhwc would have written, gathered on the fly (a 16-wide k-step stays inside
 // one filter tap because Cin % 16 == 0, so the tap is a scalar per k-step and a thread's float4 is four consecutive channels of
 // one input pixel, or zero outside the image).  No [rows, kh*kw*Cin] matrix exists in memory (9x the activation for a 3x3 layer).
-struct ConvGeom { int H, W, C, kh, kw, stride, pad, Ho, Wo; };
+struct ConvGeom { int H, W, C, kh, kw, stride, pad, Ho, Wo, dshift; };    // dshift: log2 of the INPUT dilation (0; 1 = the stride-2 layers' d input)
 
 template <int EPI, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A, int64_t lda,
@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const float* __restrict__ A
         for (int u = 0; u < 2; ++u) {
             const int row = srow0 + u * 64;
             if constexpr (CONV) {
-                const int iy = c_y[u] + ky, ix = c_x[u] + kx;
-                const bool ok = tap_ok && m0 + row < M && iy >= 0 && iy < cg.H && ix >= 0 && ix < cg.W;
+                // (d input of a strided layer: the gradient rows sit on every 2^dshift-th position of the window grid)
+                const int ny = c_y[u] + ky, nx = c_x[u] + kx, dmask = (1 << cg.dshift) - 1;
+                const int iy = ny >> cg.dshift, ix = nx >> cg.dshift;
+                const bool ok = tap_ok && m0 + row < M && ny >= 0 && nx >= 0 && ((ny | nx) & dmask) == 0 && iy < cg.H && ix < cg.W;
                 ra[u] = ok ? *reinterpret_cast<const float4*>(A + (((int64_t)c_img[u] * cg.H + iy) * cg.W + ix) * cg.C + c0)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
             } else
@@ -189,7 +191,7 @@ int launch_conv_gemm32(const float* x, int n, int H, int W_, int Cin, int kh, in
     MST_CHECK_ARG(x && Wg && out && n > 0 && H > 0 && W_ > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv_gemm: bad arguments");
     MST_CHECK_ARG(Cin % 16 == 0, "conv_gemm: Cin=%d must be a multiple of 16 (use mst_im2col_nhwc + mst_gemm otherwise)", Cin);
     MST_CHECK_ARG(Kpad >= kh * kw * Cin && Kpad % BK == 0 && ldw % 4 == 0 && ldw >= Kpad, "conv_gemm: Kpad=%d / ldw", Kpad);
-    ConvGeom cg{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1};
+    ConvGeom cg{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1, 0};
     MST_CHECK_ARG(cg.Ho > 0 && cg.Wo > 0 && (int64_t)n * cg.Ho * cg.Wo < (1ll << 31) - BM, "conv_gemm: output %d x %d x %d", n, cg.Ho, cg.Wo);
     switch (epi) {
         case MST_EPI_BIAS: return launch_conv_t<MST_EPI_BIAS>(x, cg, n, Wg, ldw, bias, out, ldc, Cout, Kpad, gamma, s);
@@ -199,6 +201,22 @@ int launch_conv_gemm32(const float* x, int n, int H, int W_, int Cin, int kh, in
     }
     mst_set_error("conv_gemm: epilogue %d unsupported (bias, bias + ReLU, residual, residual + ReLU)", epi);
     return MST_EINVAL;
+}
+
+// d input of a convolution as a convolution: dx[img][y][x][c] = sum_{ky',kx',co} dz[img][(y - pt + ky') / s][(x - pt + kx') / s][co] * Wt[c][(ky',kx',co)]
+// over the positions the division is exact for, pt = k - 1 - pad, Wt[c][(ky',kx',co)] = W[co][c][k-1-ky'][k-1-kx'] (the caller flips and
+// transposes the weight).  The same implicit GEMM with stride 1, padding pt and the gradient rows dilated by the forward stride: no
+// [rows, kh*kw*Cin] gradient matrix, no scatter with atomics.  dz [n,Ho,Wo,Cout] (Cout % 16 == 0), dx [n*H*W, Cin] overwritten.
+int launch_conv_dgrad32(const float* dz, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const float* Wt, int H, int W_,
+                        int Cin, float* dx, hipStream_t s) {
+    MST_CHECK_ARG(dz && Wt && dx && n > 0 && Ho > 0 && Wo > 0 && H > 0 && W_ > 0 && kh == kw && kh > 0 && pad >= 0 && pad < kh, "conv_dgrad: bad arguments");
+    MST_CHECK_ARG(stride == 1 || stride == 2, "conv_dgrad: stride %d (1 or 2)", stride);
+    MST_CHECK_ARG(Cout % 16 == 0, "conv_dgrad: Cout=%d must be a multiple of 16", Cout);
+    MST_CHECK_ARG((H + 2 * pad - kh) / stride + 1 == Ho && (W_ + 2 * pad - kw) / stride + 1 == Wo, "conv_dgrad: %d x %d is not the output of a %d x %d input", Ho, Wo, H, W_);
+    MST_CHECK_ARG((int64_t)n * H * W_ < (1ll << 31) - BM, "conv_dgrad: %d x %d x %d", n, H, W_);
+    ConvGeom cg{Ho, Wo, Cout, kh, kw, 1, kh - 1 - pad, H, W_, stride - 1};
+    const int K = kh * kw * Cout;
+    return launch_conv_t<MST_EPI_BIAS>(dz, cg, n, Wt, K, nullptr, dx, Cin, Cin, K, nullptr, s);
 }
 
 int launch_gemm32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,

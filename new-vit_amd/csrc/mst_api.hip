@@ -241,6 +241,12 @@ int mst_conv_gemm16(const void* x, int dtype, int n, int H, int W, int Cin, int 
                     void* out, int out_dtype, int Cout, int epilogue, mst_stream_t stream) {
     return launch_conv_gemm16(x, dtype, n, H, W, Cin, kh, kw, stride, pad, Wg, bias, out, out_dtype, Cout, epilogue, (hipStream_t)stream);
 }
+int mst_conv_dgrad(const void* dz, int dtype, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W,
+                   int Cin, float* dx, mst_stream_t stream) {
+    if (dtype == MST_F32)
+        return launch_conv_dgrad32((const float*)dz, n, Ho, Wo, Cout, kh, kw, stride, pad, (const float*)Wt, H, W, Cin, dx, (hipStream_t)stream);
+    return launch_conv_dgrad16(dz, dtype, n, Ho, Wo, Cout, kh, kw, stride, pad, Wt, H, W, Cin, dx, (hipStream_t)stream);
+}
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream) { return launch_cvt32(x, dtype, n, out, (hipStream_t)stream); }
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");

@@ -170,6 +170,10 @@ int launch_gemm16_splitk(const void* A, int dt, int64_t lda, const void* W, int6
                          int splits, int64_t split_stride, hipStream_t s);
 int launch_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, void* out, int dt, int64_t ldo, int transpose,
                  int64_t rows_pad, hipStream_t s);
+int launch_conv_dgrad32(const float* dz, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const float* Wt, int H, int W,
+                        int Cin, float* dx, hipStream_t s);
+int launch_conv_dgrad16(const void* dz, int dt, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W,
+                        int Cin, float* dx, hipStream_t s);
 int launch_cvt32(const void* x, int dt, int64_t n, float* out, hipStream_t s);
 int launch_conv_gemm16(const void* x, int dt, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
                        void* out, int cdt, int Cout, int epi, hipStream_t s);

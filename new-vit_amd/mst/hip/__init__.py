@@ -87,6 +87,7 @@ SIGNATURES = {
     "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "mst_conv_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mst_batchnorm_train": (_i, [_vp, _i64, _i, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -694,6 +695,26 @@ def conv_gemm16(x: torch.Tensor, wg: torch.Tensor, bias: Optional[torch.Tensor],
     _check(load().mst_conv_gemm16(ptr(x), dt_of(x), n, H, W, Cin, kh, kw, stride, pad, ptr(wg), ptr(bias), ptr(out), dt_of(out), Cout, epilogue,
                                   stream_of(x)), "mst_conv_gemm16")
     return out
+
+
+def conv_dgrad(dz: torch.Tensor, wt: torch.Tensor, k: int, stride: int, pad: int, H: int, W: int) -> torch.Tensor:
+    """mst_conv_dgrad: gradient of a convolution's input from dz [n,Ho,Wo,Cout] (fp32 / bf16 / fp16) and the flipped, transposed weight
+    wt [Cin, k*k*Cout] (conv_dgrad_weight) -> dx [n,H,W,Cin] fp32."""
+    _dev(dz, "conv_dgrad")
+    _dev(wt, "conv_dgrad")
+    n, Ho, Wo, Cout = dz.shape
+    Cin = wt.shape[0]
+    if wt.shape[1] != k * k * Cout or wt.dtype != dz.dtype:
+        raise ValueError(f"conv_dgrad: weight {tuple(wt.shape)} {wt.dtype} does not match k*k*Cout = {k * k * Cout} of {dz.dtype}")
+    dx = torch.empty((n, H, W, Cin), dtype=torch.float32, device=dz.device)
+    _check(load().mst_conv_dgrad(ptr(dz), dt_of(dz), n, Ho, Wo, Cout, k, k, stride, pad, ptr(wt), H, W, Cin, ptr(dx), stream_of(dz)), "mst_conv_dgrad")
+    return dx
+
+
+def conv_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """[Cout, Cin, k, k] -> the operand mst_conv_dgrad multiplies by: [Cin, (ky', kx', co)] with both kernel axes flipped."""
+    Cout, Cin, k, _ = weight.shape
+    return weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, k * k * Cout).to(dtype).contiguous()
 
 
 def cvt32(x: torch.Tensor) -> torch.Tensor:

@@ -19,6 +19,7 @@ backward instead of being kept.  Checked against torch.autograd of oracle/resnet
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -94,6 +95,11 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
     G.put(conv.weight, dw.contiguous())
     if not need_dx:
         return None
+    if Cout % 16 == 0 and Cin % 4 == 0 and stride in (1, 2) and os.environ.get("MST_CONV_IM2COL", "0") != "1":
+        # d input as a convolution of dz with the flipped, transposed weight (mst_conv_dgrad): no gradient matrix, no atomics
+        del col
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        return hip.conv_dgrad(dz.view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight), k, stride, pad, H, W)
     hip.gemm_ex(dz, wg, col, rows, kpad, Cout, sa=(Cout, 1), sb=(kpad, 1), sc=(kpad, 1))      # dcol overwrites col
     dx = torch.zeros_like(x)
     return hip.col2im_nhwc(col, dx, k, k, stride, pad)

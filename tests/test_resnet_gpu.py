@@ -368,6 +368,28 @@ def test_16_bit_inference_backbone_against_the_fp32_one(cdt, tol, model):
         ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, compute_dtype="fp8")
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw", [
+    (3, 64, 64, 3, 1, 1, (16, 15)), (2, 64, 128, 3, 2, 1, (41, 37)), (2, 64, 128, 3, 2, 1, (12, 10)), (5, 128, 256, 1, 2, 0, (35, 27)),
+    (2, 256, 64, 1, 1, 0, (9, 7)), (2, 128, 128, 3, 1, 1, (20, 13)), (1, 200, 64, 3, 2, 1, (11, 14))])
+def test_input_gradient_as_a_convolution(dt, n, cin, cout, k, stride, pad, hw):
+    """mst_conv_dgrad: the gradient of a convolution's input computed as a convolution of dz (dilated by the stride) with the flipped,
+    transposed weight -- against torch.autograd of F.conv2d on the same (rounded) operands; odd sizes where the last input rows and
+    columns fall outside every window included."""
+    import torch.nn.functional as F
+    from mst import hip
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    g = torch.Generator().manual_seed(n * 100 + cin + cout + k + stride)
+    x = torch.randn(n, cin, *hw, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(tdt)
+    y = F.conv2d(x, w.double(), stride=stride, padding=pad)
+    dz = (torch.randn(y.shape, generator=g)).to(tdt)
+    y.backward(dz.double())
+    got = hip.conv_dgrad(dz.permute(0, 2, 3, 1).contiguous().cuda(), hip.conv_dgrad_weight(w.cuda(), tdt), k, stride, pad, *hw)
+    assert got.shape == (n, *hw, cin) and got.dtype == torch.float32
+    assert rel_l2(got.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-6                      # same operands, fp32 accumulation either way
+
+
 def test_implicit_gemm_convolution_rejects_what_it_cannot_gather():
     from mst import hip
     x = torch.zeros(1, 4, 4, 3, device="cuda")
