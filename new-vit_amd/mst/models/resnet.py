@@ -166,6 +166,12 @@ class ResNet(BasicClassifier):
         if cdt not in ("fp32", "bf16", "fp16"):
             raise ValueError("ResNet: compute_dtype must be 'fp32', 'bf16' or 'fp16'")
         self.compute_dtype_name = cdt
+        # build-specific: MFMA operand type of the TRAINING step's convolutions and their input gradients ('fp32' default | 'bf16' | 'fp16';
+        # fp32 accumulation and storage; the reference trains under Trainer(precision='16-mixed'), scripts/main_train.py:110-123)
+        tp = str(kwargs.pop("train_precision", os.environ.get("MST_TRAIN_PRECISION", "fp32"))).lower()
+        if tp not in ("fp32", "bf16", "fp16"):
+            raise ValueError("ResNet: train_precision must be 'fp32', 'bf16' or 'fp16'")
+        self.train_precision = tp
         super().__init__(in_ch, out_ch, spatial_dims, **kwargs)
         self.attention_maps = []
         if spatial_dims != 2:

@@ -44,16 +44,23 @@ def _gemm_weight(conv, sum_in: bool) -> torch.Tensor:
 
 
 def _conv_bn_fwd(x: torch.Tensor, conv, bn, k: int, stride: int, pad: int, sum_in: bool, residual: Optional[torch.Tensor],
-                 relu: bool):
-    """x [n,H,W,C] -> y [n,Ho,Wo,Cout] plus the record the backward needs."""
-    n, H, W, _ = x.shape
+                 relu: bool, mp: Optional[torch.dtype] = None):
+    """x [n,H,W,C] -> y [n,Ho,Wo,Cout] plus the record the backward needs.  mp (train_precision bf16 / fp16): the convolution and its
+    input gradient on 16-bit MFMA operands (fp32 accumulation; activations, BatchNorm, weight gradient and everything stored stay fp32) --
+    the reference's Trainer(precision='16-mixed') for F.conv2d."""
+    n, H, W, Cin = x.shape
     wg = _gemm_weight(conv, sum_in)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    z = _conv(x, wg, None, k, stride, pad, wg.shape[1], hip.EPI_BIAS)        # implicit GEMM behind the stem
+    mp = mp if (mp is not None and Cin % 64 == 0 and wg.shape[0] % 64 == 0) else None
+    if mp is not None:
+        z = hip.conv_gemm16(hip.cvt16(x.view(-1, Cin), mp).view(x.shape), hip.cvt16(wg, mp), None, k, k, stride, pad, epilogue=hip.EPI_BIAS,
+                            out_dtype=torch.float32)
+    else:
+        z = _conv(x, wg, None, k, stride, pad, wg.shape[1], hip.EPI_BIAS)    # implicit GEMM behind the stem
     y, mean, rstd = hip.batchnorm_train(z, bn, residual, relu)
     bn.num_batches_tracked += 1
     rec = {"x": x, "z": z, "y": y if relu else None, "mean": mean, "rstd": rstd, "wg": wg, "k": k, "stride": stride, "pad": pad,
-           "sum_in": sum_in, "relu": relu, "conv": conv, "bn": bn}
+           "sum_in": sum_in, "relu": relu, "conv": conv, "bn": bn, "mp": mp}
     return y.view(n, Ho, Wo, wg.shape[0]), rec
 
 
@@ -99,41 +106,44 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
         # d input as a convolution of dz with the flipped, transposed weight (mst_conv_dgrad): no gradient matrix, no atomics
         del col
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        mp = rec["mp"]
+        if mp is not None:
+            return hip.conv_dgrad(hip.cvt16(dz, mp).view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight, mp), k, stride, pad, H, W)
         return hip.conv_dgrad(dz.view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight), k, stride, pad, H, W)
     hip.gemm_ex(dz, wg, col, rows, kpad, Cout, sa=(Cout, 1), sb=(kpad, 1), sc=(kpad, 1))      # dcol overwrites col
     dx = torch.zeros_like(x)
     return hip.col2im_nhwc(col, dx, k, k, stride, pad)
 
 
-def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool):
+def backbone_fwd(m, x_nhwc: torch.Tensor, sum_in: bool, mp: Optional[torch.dtype] = None):
     """torchvision resnet{18,34,50,101,152} forward in train mode up to the pooled features [n, 512 or 2048]."""
     sv = {"units": []}
-    y, sv["stem"] = _conv_bn_fwd(x_nhwc.contiguous(), m.conv1, m.bn1, 7, 2, 3, sum_in, None, True)
+    y, sv["stem"] = _conv_bn_fwd(x_nhwc.contiguous(), m.conv1, m.bn1, 7, 2, 3, sum_in, None, True, mp)
     sv["pool_in"] = y
     y = hip.maxpool_nhwc(y)
     for li in range(4):
         for blk in getattr(m, f"layer{li + 1}"):
             n, H, W, Cin = y.shape
             if hasattr(blk, "conv3"):                                    # bottleneck: 1x1 -> 3x3 (stride) -> 1x1 + residual
-                h0, r0 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 1, 1, 0, False, None, True)
-                h1, r1 = _conv_bn_fwd(h0, blk.conv2, blk.bn2, 3, blk.stride, 1, False, None, True)
+                h0, r0 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 1, 1, 0, False, None, True, mp)
+                h1, r1 = _conv_bn_fwd(h0, blk.conv2, blk.bn2, 3, blk.stride, 1, False, None, True, mp)
                 rd = None
                 if hasattr(blk, "downsample"):
-                    idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False)
+                    idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False, mp)
                     idt = idt.reshape(-1, idt.shape[-1])
                 else:
                     idt = y.reshape(n * H * W, Cin)
-                y, r2 = _conv_bn_fwd(h1, blk.conv3, blk.bn3, 1, 1, 0, False, idt, True)
+                y, r2 = _conv_bn_fwd(h1, blk.conv3, blk.bn3, 1, 1, 0, False, idt, True, mp)
                 sv["units"].append((r0, r2, rd, r1))
                 continue
-            h1, r1 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 3, blk.stride, 1, False, None, True)
+            h1, r1 = _conv_bn_fwd(y, blk.conv1, blk.bn1, 3, blk.stride, 1, False, None, True, mp)
             rd = None
             if hasattr(blk, "downsample"):
-                idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False)
+                idt, rd = _conv_bn_fwd(y, blk.downsample[0], blk.downsample[1], 1, blk.stride, 0, False, None, False, mp)
                 idt = idt.reshape(-1, idt.shape[-1])
             else:
                 idt = y.reshape(n * H * W, Cin)
-            y, r2 = _conv_bn_fwd(h1, blk.conv2, blk.bn2, 3, 1, 1, False, idt, True)
+            y, r2 = _conv_bn_fwd(h1, blk.conv2, blk.bn2, 3, 1, 1, False, idt, True, mp)
             sv["units"].append((r1, r2, rd, None))
     sv["last"] = y
     return hip.avgpool_nhwc(y), sv
@@ -162,7 +172,7 @@ def backbone_bwd(G: _Grads, sv, dfeat: torch.Tensor):
 # ---- whole models ------------------------------------------------------------------------------------------------------
 def forward_train(model, x_nhwc: torch.Tensor, sum_in: bool, B: Optional[int], D: Optional[int], mask: Optional[torch.Tensor]):
     """B/D given: ResNetSliceTrans (features -> slice transformer -> linear); else plain ResNet (features -> fc)."""
-    feat, sv = backbone_fwd(model.model, x_nhwc, sum_in)
+    feat, sv = backbone_fwd(model.model, x_nhwc, sum_in, {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(model, "train_precision", "fp32")])
     sv["feat"] = feat
     if B is None:
         fc = model.model.fc
