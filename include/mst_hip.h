@@ -153,6 +153,11 @@ int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stre
  * with stride 1, padding k - 1 - pad and the gradient rows dilated by the forward stride (1 or 2), instead of dZ . W into a [rows, kh*kw*Cin]
  * matrix and a scatter with atomics (mst_col2im_nhwc).  dz [n,Ho,Wo,Cout] and Wt [Cin, kh*kw*Cout] of `dtype` (f32: Cout % 16 == 0; bf16 / f16:
  * Cout % 64 == 0), Wt[c][(ky',kx',co)] = W[co][c][k-1-ky'][k-1-kx']; dx fp32 [n*H*W, Cin], overwritten. */
+/* mst_conv_wgrad: d weight of a convolution as an implicit GEMM: part[z][co][(ky,kx,c)] = sum over the output pixels [z rps, (z + 1) rps) of
+ * dz[r][co] * x[pixel(r) + (ky,kx)][c] -- nsplit partial products fp32 [nsplit, Cout, kh*kw*Cin] (the caller sums them: mst_colsum), B operand
+ * gathered from x [n,H,W,Cin] (no im2col matrix).  dz [n*Ho*Wo, Cout] fp32; Cin % 64 == 0, Cout % 4 == 0, nsplit * rows_per_split >= rows. */
+int mst_conv_wgrad(const float* dz, const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
+                   int nsplit, int64_t rows_per_split, mst_stream_t stream);
 int mst_conv_dgrad(const void* dz, int dtype, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W,
                    int Cin, float* dx, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "mst_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "mst_conv_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -709,6 +710,25 @@ def conv_dgrad(dz: torch.Tensor, wt: torch.Tensor, k: int, stride: int, pad: int
     dx = torch.empty((n, H, W, Cin), dtype=torch.float32, device=dz.device)
     _check(load().mst_conv_dgrad(ptr(dz), dt_of(dz), n, Ho, Wo, Cout, k, k, stride, pad, ptr(wt), H, W, Cin, ptr(dx), stream_of(dz)), "mst_conv_dgrad")
     return dx
+
+
+def conv_wgrad(dz: torch.Tensor, x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    """mst_conv_wgrad + mst_colsum: gradient of a convolution's weight from dz [n*Ho*Wo, Cout] and the input x [n,H,W,Cin] (fp32, Cin % 64 == 0)
+    -> [Cout, k*k*Cin] in (ky, kx, c) order.  The pixels are split into enough partial products to fill the chip."""
+    _dev(dz, "conv_wgrad")
+    _dev(x, "conv_wgrad")
+    n, H, W, Cin = x.shape
+    rows, Cout = dz.shape
+    K = k * k * Cin
+    tiles = (K // 64) * ((Cout + 63) // 64)
+    nsplit = max(1, min(1024, 2048 // tiles, (rows + 255) // 256))
+    rps = (-(-rows // nsplit) + 15) // 16 * 16
+    nsplit = -(-rows // rps)
+    part = torch.empty((nsplit, Cout * K), dtype=torch.float32, device=dz.device)
+    _check(load().mst_conv_wgrad(ptr(dz), ptr(x), n, H, W, Cin, k, k, stride, pad, Cout, ptr(part), nsplit, rps, stream_of(dz)), "mst_conv_wgrad")
+    if nsplit == 1:
+        return part.view(Cout, K)
+    return colsum(part, torch.zeros(Cout * K, dtype=torch.float32, device=dz.device)).view(Cout, K)
 
 
 def conv_dgrad_weight(weight: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:

@@ -87,14 +87,19 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
     dz, dg, db = hip.batchnorm_bwd(z, rec["mean"], rec["rstd"], bn.weight.detach(), dy)
     G.put(bn.weight, dg)
     G.put(bn.bias, db)
-    col = hip.im2col_nhwc(x, k, k, stride, pad, kpad)
-    hw = rows // n
-    s1, s2 = _split(n, hw)
-    part = torch.empty((s1 * s2, Cout * kpad), dtype=torch.float32, device=dev)
-    ch = hw // s2                                                        # rows per partial product
-    hip.gemm_ex(dz, col, part, Cout, kpad, ch, sa=(1, Cout), sb=(kpad, 1), sc=(kpad, 1), nb=(s1, s2), ba=(hw * Cout, ch * Cout),
-                bb=(hw * kpad, ch * kpad), bc=(s2 * Cout * kpad, Cout * kpad))
-    dwg = hip.colsum(part, torch.zeros(Cout * kpad, dtype=torch.float32, device=dev)).view(Cout, kpad)
+    implicit = os.environ.get("MST_CONV_IM2COL", "0") != "1"
+    col = None
+    if implicit and Cin % 64 == 0 and Cout % 4 == 0:
+        dwg = hip.conv_wgrad(dz, x, k, stride, pad)                      # implicit GEMM: no im2col matrix (fp32 whatever train_precision says)
+    else:
+        col = hip.im2col_nhwc(x, k, k, stride, pad, kpad)
+        hw = rows // n
+        s1, s2 = _split(n, hw)
+        part = torch.empty((s1 * s2, Cout * kpad), dtype=torch.float32, device=dev)
+        ch = hw // s2                                                    # rows per partial product
+        hip.gemm_ex(dz, col, part, Cout, kpad, ch, sa=(1, Cout), sb=(kpad, 1), sc=(kpad, 1), nb=(s1, s2), ba=(hw * Cout, ch * Cout),
+                    bb=(hw * kpad, ch * kpad), bc=(s2 * Cout * kpad, Cout * kpad))
+        dwg = hip.colsum(part, torch.zeros(Cout * kpad, dtype=torch.float32, device=dev)).view(Cout, kpad)
     K = k * k * Cin
     dw = dwg[:, :K].reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     if rec["sum_in"]:
@@ -102,7 +107,7 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
     G.put(conv.weight, dw.contiguous())
     if not need_dx:
         return None
-    if Cout % 16 == 0 and Cin % 4 == 0 and stride in (1, 2) and os.environ.get("MST_CONV_IM2COL", "0") != "1":
+    if Cout % 16 == 0 and Cin % 4 == 0 and stride in (1, 2) and implicit:
         # d input as a convolution of dz with the flipped, transposed weight (mst_conv_dgrad): no gradient matrix, no atomics
         del col
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -110,6 +115,8 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
         if mp is not None:
             return hip.conv_dgrad(hip.cvt16(dz, mp).view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight, mp), k, stride, pad, H, W)
         return hip.conv_dgrad(dz.view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight), k, stride, pad, H, W)
+    if col is None:
+        col = torch.empty((rows, kpad), dtype=torch.float32, device=dev)
     hip.gemm_ex(dz, wg, col, rows, kpad, Cout, sa=(Cout, 1), sb=(kpad, 1), sc=(kpad, 1))      # dcol overwrites col
     dx = torch.zeros_like(x)
     return hip.col2im_nhwc(col, dx, k, k, stride, pad)

@@ -390,6 +390,25 @@ def test_input_gradient_as_a_convolution(dt, n, cin, cout, k, stride, pad, hw):
     assert rel_l2(got.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-6                      # same operands, fp32 accumulation either way
 
 
+@pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw", [
+    (3, 64, 64, 3, 1, 1, (16, 15)), (2, 64, 128, 3, 2, 1, (41, 37)), (5, 128, 256, 1, 2, 0, (35, 27)), (2, 256, 68, 1, 1, 0, (9, 7)),
+    (9, 128, 128, 3, 1, 1, (20, 13)), (1, 192, 64, 3, 2, 1, (11, 14)), (70, 64, 64, 3, 1, 1, (30, 28))])
+def test_weight_gradient_as_an_implicit_gemm(n, cin, cout, k, stride, pad, hw):
+    """mst_conv_wgrad (+ mst_colsum over its partial products): the gradient of a convolution's weight with the B operand gathered from the
+    NHWC activation -- against torch.autograd of F.conv2d in fp64; one and many splits, ragged last split, Cout no multiple of 64."""
+    import torch.nn.functional as F
+    from mst import hip
+    g = torch.Generator().manual_seed(n * 100 + cin + cout + k + stride)
+    x = torch.randn(n, cin, *hw, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) / math.sqrt(cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x.double(), w, stride=stride, padding=pad)
+    dz = torch.randn(y.shape, generator=g)
+    y.backward(dz.double())
+    got = hip.conv_wgrad(dz.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(), k, stride, pad)
+    assert got.shape == (cout, k * k * cin)
+    assert rel_l2(got.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), w.grad) < 2e-6
+
+
 def test_implicit_gemm_convolution_rejects_what_it_cannot_gather():
     from mst import hip
     x = torch.zeros(1, 4, 4, 3, device="cuda")

@@ -58,12 +58,12 @@ def main():
             train_case(f"DinoV2ClassifierSlice training step ({prec} linear products, HIP backward)", m, shape)
     if "--only-dino-c1" in sys.argv or "--only-dino-2x32" in sys.argv:
         return
-    for shape in ((2, 1, 32, 224, 224),):
+    for shape in (() if "--c3-only" in sys.argv else ((2, 1, 32, 224, 224),)):
         m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34)
         m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
         train_case("ResNetSliceTrans(resnet34) training step (fp32 HIP backward)", m, shape)
     if "--c3" in sys.argv:                               # BASELINE configs[3] per-GPU shape: one LIDC-shaped 128 x 512 x 512 volume
-        for prec in (("fp32", "bf16", "fp16") if "--mixed" in sys.argv else ("fp32",)):
+        for prec in (("fp32", "bf16", "fp16") if "--mixed" in sys.argv else ("fp16",) if "--fp16" in sys.argv else ("fp32",)):
             m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=34, train_precision=prec)
             m.load_state_dict(synth.synth_resnet_state_dict(0, 34, 2), strict=True)
             train_case(f"ResNetSliceTrans(resnet34) training step ({prec} convolutions), BASELINE configs[3] shape", m, (1, 1, 128, 512, 512), n=3)

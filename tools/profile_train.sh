@@ -4,7 +4,7 @@ TAG=${1:-x}
 OUT=$PWD/gpurun_out/train_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py ${2:---only-dino-c1} $3 > $OUT/stdout.log 2> $OUT/stderr.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train -- python3 $GRAFT_REPO_ROOT/tools/bench_train.py ${2:---only-dino-c1} $3 $4 $5 > $OUT/stdout.log 2> $OUT/stderr.log
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/train_kernel_stats.csv")))
