@@ -158,6 +158,10 @@ int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stre
  * gathered from x [n,H,W,Cin] (no im2col matrix).  dz [n*Ho*Wo, Cout] fp32; Cin % 64 == 0, Cout % 4 == 0, nsplit * rows_per_split >= rows. */
 int mst_conv_wgrad(const float* dz, const float* x, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
                    int nsplit, int64_t rows_per_split, mst_stream_t stream);
+/* mst_conv_wgrad16: the same partial products from 16-bit operands (dz and x bf16 / f16; Cin % 64 == 0, Cout % 64 == 0, rows_per_split % 64 == 0):
+ * pixel-major tiles in LDS, fragments through the hardware-transposing LDS read. */
+int mst_conv_wgrad16(const void* dz, const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
+                     int nsplit, int64_t rows_per_split, mst_stream_t stream);
 int mst_conv_dgrad(const void* dz, int dtype, int n, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, const void* Wt, int H, int W,
                    int Cin, float* dx, mst_stream_t stream);
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream);

@@ -149,6 +149,139 @@ __global__ __launch_bounds__(256) void conv16_kernel(const T* __restrict__ x, Co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// d weight on 16-bit operands: dW[co][(ky,kx,c)] = sum over output pixels r of dz[r][co] * x[pixel(r) + (ky,kx)][c] (see k_wgrad.hip for the fp32
+// form).  Both operands are stored pixel-major ([r][co], [pixel][c]) but the MFMA wants 8 consecutive K values (pixels) per lane: the tiles
+// land in LDS as they are (64 pixels x 64 columns images, LDS-DMA, the x rows gathered per tap with the zero page for padding) and the
+// fragments are read with the hardware transpose (ds_read_b64_tr_b16), the way the attention kernel reads V^T (k_attn16.hip): the same
+// lane map on both operands permutes K identically, so the sum is unchanged.  128 x 128 output tile per workgroup (4 waves x 64 x 64,
+// v_mfma_f32_32x32x16), K-step 64 pixels, LDS double buffer; pixels split over blockIdx.z into fp32 partial products.
+struct Wgrad16Args {
+    int Cout, Kc, H, W, Cin, kw, stride, pad, Ho, Wo;
+    int64_t rows, rows_per_split;
+};
+
+template <typename T>
+__device__ __forceinline__ typename V8<T>::type tr_frag(const char* p) {       // p, p + 8 rows: elements j = 0..3 | 4..7 of the fragment
+    typedef typename V8<T>::type vec8;
+    union { struct { s16x4 lo, hi; } s; vec8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * 128));
+    return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ part, Wgrad16Args g) {
+    typedef typename V8<T>::type vec8;
+    constexpr int IMG = 64 * 128;                                     // one image: 64 pixels x 64 columns x 2 B
+    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * IMG];   // [buf][A sub 0, A sub 1, B sub 0, B sub 1]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t r_begin = (int64_t)blockIdx.z * g.rows_per_split;
+    const int64_t r_end = r_begin + g.rows_per_split < g.rows ? r_begin + g.rows_per_split : g.rows;
+
+    // ---- staging: wave w fills image w of a stage (0, 1: dz columns m0 + 64 w ..; 2, 3: x columns of (tap, c) n0 + 64 (w - 2) ..), eight
+    // 1 KiB pieces of 8 pixels each; lane -> pixel row (lane >> 3) of the piece, LDS slot lane & 7, source chunk permuted like the V image
+    const bool is_b = wave >= 2;
+    const int sub = wave & 1;
+    const int col0 = is_b ? n0 + 64 * sub : m0 + 64 * sub;            // first column of this image
+    const bool img_ok = is_b ? col0 < g.Kc : col0 < g.Cout;           // the last tile's second image may lie beyond the matrix
+    const int tap = is_b ? col0 / g.Cin : 0, c0 = is_b ? col0 - tap * g.Cin : col0;
+    const int ky = tap / g.kw, kx = tap - ky * g.kw;
+    const int prow = lane >> 3;
+    // pixel walk of the B loader: (img, oy, ox) of pixel r_begin + prow, advanced by 8 pixels per piece
+    int64_t r_lane = r_begin + prow;
+    int p_img, p_oy, p_ox;
+    {
+        const int hw = g.Ho * g.Wo;
+        p_img = (int)(r_lane / hw);
+        const int rem = (int)(r_lane - (int64_t)p_img * hw);
+        p_oy = rem / g.Wo;
+        p_ox = rem - p_oy * g.Wo;
+    }
+    const char* const zsrc = conv16_zero_page + ((lane & 7) << 4);
+    auto stage = [&](int buf) {
+        char* dst = smem + (buf * 4 + wave) * IMG;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+            const int row = p8 * 8 + prow;
+            const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
+            const char* src = zsrc;
+            if (img_ok && r_lane < r_end) {
+                if (!is_b) {
+                    src = reinterpret_cast<const char*>(dz + r_lane * g.Cout + c0 + chunk * 8);
+                } else {
+                    const int iy = p_oy * g.stride - g.pad + ky, ix = p_ox * g.stride - g.pad + kx;
+                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                        src = reinterpret_cast<const char*>(x + (((int64_t)p_img * g.H + iy) * g.W + ix) * g.Cin + c0 + chunk * 8);
+                }
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p8 * 1024), 16, 0, 0);
+            r_lane += 8;
+            p_ox += 8;
+            while (p_ox >= g.Wo) { p_ox -= g.Wo; ++p_oy; }
+            while (p_oy >= g.Ho) { p_oy -= g.Ho; ++p_img; }
+        }
+    };
+
+    // ---- fragment addresses (k_attn16.hip's V map): 16-lane group reads 4 pixels x 16 columns, transposed by the hardware
+    const int h2 = lane >> 5, vi = lane & 15;
+    const int vrow = 4 * h2 + (vi >> 2);
+    const int vsw = ((vrow >> 1) & 1) << 2;
+    const int vchunk = ((lane >> 4) & 1) * 2 + ((vi & 3) >> 1);
+    const int v_lane_off = vrow * 128 + (vi & 1) * 8;
+    int foff[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) foff[db] = v_lane_off + (((db * 4 + vchunk) ^ vsw) * 16);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    int buf = 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // this stage has landed; every wave is done reading the other buffer
+        if (r0 + 64 < r_end) stage(buf ^ 1);
+        const char* Ai = smem + (buf * 4 + wm) * IMG;
+        const char* Bi = smem + (buf * 4 + 2 + wn) * IMG;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            vec8 af[2], bf[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                af[db] = tr_frag<T>(Ai + ks * 16 * 128 + foff[db]);
+                bf[db] = tr_frag<T>(Bi + ks * 16 * 128 + foff[db]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        buf ^= 1;
+    }
+    float* C = part + (int64_t)blockIdx.z * g.Cout * g.Kc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.Kc) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.Cout) C[(int64_t)row * g.Kc + col] = acc[i][j][r];
+            }
+        }
+}
+
 template <typename T, int BN, int EPI, typename OutT>
 int launch_k(const void* x, const Conv16Geom& g, int n, const void* Wg, int64_t ldw, const float* bias, void* C, int64_t ldc, int N,
              hipStream_t s) {
@@ -223,4 +356,22 @@ int launch_conv_dgrad16(const void* dz, int dt, int n, int Ho, int Wo, int Cout,
                       : launch_k<bf16_t, 128, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s);
     return narrow ? launch_k<f16_t, 64, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s)
                   : launch_k<f16_t, 128, MST_EPI_BIAS, float>(dz, g, n, Wt, ldw, nullptr, dx, Cin, Cin, s);
+}
+
+// part[z][co][(ky,kx,c)] on 16-bit operands: dz [n*Ho*Wo, Cout] and x [n,H,W,Cin] of type dt (Cin % 64 == 0, Cout % 64 == 0); see launch_conv_wgrad32.
+int launch_conv_wgrad16(const void* dz, const void* x, int dt, int n, int H, int W_, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
+                        int nsplit, int64_t rows_per_split, hipStream_t s) {
+    MST_CHECK_ARG(dz && x && part && n > 0 && H > 0 && W_ > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv_wgrad16: bad arguments");
+    MST_CHECK_ARG(dt == MST_BF16 || dt == MST_F16, "conv_wgrad16: operand dtype %d (bf16 / f16)", dt);
+    MST_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0, "conv_wgrad16: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
+    MST_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "conv_wgrad16: bases must be 16-byte aligned");
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W_ + 2 * pad - kw) / stride + 1;
+    const int64_t rows = (int64_t)n * Ho * Wo;
+    MST_CHECK_ARG(Ho > 0 && Wo > 0 && nsplit > 0 && nsplit <= 65535 && rows_per_split > 0 && rows_per_split % 64 == 0 && (int64_t)nsplit * rows_per_split >= rows,
+                  "conv_wgrad16: %d splits of %lld rows (a multiple of 64) do not cover %lld", nsplit, (long long)rows_per_split, (long long)rows);
+    Wgrad16Args g{Cout, kh * kw * Cin, H, W_, Cin, kw, stride, pad, Ho, Wo, rows, rows_per_split};
+    const dim3 grid((g.Kc + 127) / 128, (Cout + 127) / 128, nsplit);
+    if (dt == MST_BF16) wgrad16_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const bf16_t*)dz, (const bf16_t*)x, part, g);
+    else wgrad16_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const f16_t*)dz, (const f16_t*)x, part, g);
+    return mst_check_launch("conv_wgrad16");
 }

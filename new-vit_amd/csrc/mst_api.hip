@@ -251,6 +251,10 @@ int mst_conv_wgrad(const float* dz, const float* x, int n, int H, int W, int Cin
                    int nsplit, int64_t rows_per_split, mst_stream_t stream) {
     return launch_conv_wgrad32(dz, x, n, H, W, Cin, kh, kw, stride, pad, Cout, part, nsplit, rows_per_split, (hipStream_t)stream);
 }
+int mst_conv_wgrad16(const void* dz, const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
+                     int nsplit, int64_t rows_per_split, mst_stream_t stream) {
+    return launch_conv_wgrad16(dz, x, dtype, n, H, W, Cin, kh, kw, stride, pad, Cout, part, nsplit, rows_per_split, (hipStream_t)stream);
+}
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream) { return launch_cvt32(x, dtype, n, out, (hipStream_t)stream); }
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
     "mst_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
+    "mst_conv_wgrad16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "mst_conv_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mst_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mst_avgpool_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -713,19 +714,28 @@ def conv_dgrad(dz: torch.Tensor, wt: torch.Tensor, k: int, stride: int, pad: int
 
 
 def conv_wgrad(dz: torch.Tensor, x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
-    """mst_conv_wgrad + mst_colsum: gradient of a convolution's weight from dz [n*Ho*Wo, Cout] and the input x [n,H,W,Cin] (fp32, Cin % 64 == 0)
-    -> [Cout, k*k*Cin] in (ky, kx, c) order.  The pixels are split into enough partial products to fill the chip."""
+    """mst_conv_wgrad(16) + mst_colsum: gradient of a convolution's weight from dz [n*Ho*Wo, Cout] and the input x [n,H,W,Cin] (both fp32, or
+    both bf16 / fp16; Cin % 64 == 0) -> fp32 [Cout, k*k*Cin] in (ky, kx, c) order.  The pixels are split into enough partial products to fill
+    the chip."""
     _dev(dz, "conv_wgrad")
     _dev(x, "conv_wgrad")
     n, H, W, Cin = x.shape
     rows, Cout = dz.shape
     K = k * k * Cin
-    tiles = (K // 64) * ((Cout + 63) // 64)
+    lo = dz.dtype != torch.float32
+    if x.dtype != dz.dtype:
+        raise ValueError(f"conv_wgrad: dz is {dz.dtype}, x is {x.dtype}")
+    tile, step = (128, 64) if lo else (64, 16)
+    tiles = ((K + tile - 1) // tile) * ((Cout + tile - 1) // tile)
     nsplit = max(1, min(1024, 2048 // tiles, (rows + 255) // 256))
-    rps = (-(-rows // nsplit) + 15) // 16 * 16
+    rps = (-(-rows // nsplit) + step - 1) // step * step
     nsplit = -(-rows // rps)
     part = torch.empty((nsplit, Cout * K), dtype=torch.float32, device=dz.device)
-    _check(load().mst_conv_wgrad(ptr(dz), ptr(x), n, H, W, Cin, k, k, stride, pad, Cout, ptr(part), nsplit, rps, stream_of(dz)), "mst_conv_wgrad")
+    if lo:
+        _check(load().mst_conv_wgrad16(ptr(dz), ptr(x), dt_of(dz), n, H, W, Cin, k, k, stride, pad, Cout, ptr(part), nsplit, rps, stream_of(dz)),
+               "mst_conv_wgrad16")
+    else:
+        _check(load().mst_conv_wgrad(ptr(dz), ptr(x), n, H, W, Cin, k, k, stride, pad, Cout, ptr(part), nsplit, rps, stream_of(dz)), "mst_conv_wgrad")
     if nsplit == 1:
         return part.view(Cout, K)
     return colsum(part, torch.zeros(Cout * K, dtype=torch.float32, device=dz.device)).view(Cout, K)

@@ -46,7 +46,7 @@ def _gemm_weight(conv, sum_in: bool) -> torch.Tensor:
 def _conv_bn_fwd(x: torch.Tensor, conv, bn, k: int, stride: int, pad: int, sum_in: bool, residual: Optional[torch.Tensor],
                  relu: bool, mp: Optional[torch.dtype] = None):
     """x [n,H,W,C] -> y [n,Ho,Wo,Cout] plus the record the backward needs.  mp (train_precision bf16 / fp16): the convolution and its
-    input gradient on 16-bit MFMA operands (fp32 accumulation; activations, BatchNorm, weight gradient and everything stored stay fp32) --
+    two gradients on 16-bit MFMA operands (fp32 accumulation; activations, BatchNorm and everything stored stay fp32) --
     the reference's Trainer(precision='16-mixed') for F.conv2d."""
     n, H, W, Cin = x.shape
     wg = _gemm_weight(conv, sum_in)
@@ -89,8 +89,12 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
     G.put(bn.bias, db)
     implicit = os.environ.get("MST_CONV_IM2COL", "0") != "1"
     col = None
-    if implicit and Cin % 64 == 0 and Cout % 4 == 0:
-        dwg = hip.conv_wgrad(dz, x, k, stride, pad)                      # implicit GEMM: no im2col matrix (fp32 whatever train_precision says)
+    mp = rec["mp"]
+    dz16 = hip.cvt16(dz, mp) if mp is not None else None                # shared by the two gradients
+    if implicit and mp is not None and Cin % 64 == 0 and Cout % 64 == 0:
+        dwg = hip.conv_wgrad(dz16, hip.cvt16(x.view(-1, Cin), mp).view(x.shape), k, stride, pad)     # 16-bit operands, fp32 partial products
+    elif implicit and Cin % 64 == 0 and Cout % 4 == 0:
+        dwg = hip.conv_wgrad(dz, x, k, stride, pad)                      # implicit GEMM: no im2col matrix
     else:
         col = hip.im2col_nhwc(x, k, k, stride, pad, kpad)
         hw = rows // n
@@ -111,9 +115,8 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
         # d input as a convolution of dz with the flipped, transposed weight (mst_conv_dgrad): no gradient matrix, no atomics
         del col
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        mp = rec["mp"]
         if mp is not None:
-            return hip.conv_dgrad(hip.cvt16(dz, mp).view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight, mp), k, stride, pad, H, W)
+            return hip.conv_dgrad(dz16.view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight, mp), k, stride, pad, H, W)
         return hip.conv_dgrad(dz.view(n, Ho, Wo, Cout), hip.conv_dgrad_weight(conv.weight), k, stride, pad, H, W)
     if col is None:
         col = torch.empty((rows, kpad), dtype=torch.float32, device=dev)

@@ -390,6 +390,28 @@ def test_input_gradient_as_a_convolution(dt, n, cin, cout, k, stride, pad, hw):
     assert rel_l2(got.permute(0, 3, 1, 2).cpu(), x.grad) < 2e-6                      # same operands, fp32 accumulation either way
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw", [
+    (3, 64, 64, 3, 1, 1, (16, 15)), (2, 64, 128, 3, 2, 1, (41, 37)), (5, 128, 256, 1, 2, 0, (35, 27)), (2, 256, 64, 1, 1, 0, (9, 7)),
+    (9, 128, 192, 3, 1, 1, (20, 13)), (1, 192, 64, 3, 2, 1, (11, 14)), (70, 64, 64, 3, 1, 1, (30, 28)), (6, 512, 512, 3, 1, 1, (7, 7))])
+def test_weight_gradient_on_16_bit_operands(dt, n, cin, cout, k, stride, pad, hw):
+    """mst_conv_wgrad16: pixel-major 16-bit tiles in LDS, both MFMA operands through the hardware-transposing LDS read, x rows gathered per
+    tap with the zero page -- against fp64 autograd of F.conv2d on the SAME rounded operands (fp32 accumulation either way); images narrower
+    than a DMA piece (7 x 7), ragged splits, column tiles that end inside the 128-wide tile (K = 576, Cout = 64 / 192)."""
+    import torch.nn.functional as F
+    from mst import hip
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    g = torch.Generator().manual_seed(n * 100 + cin + cout + k + stride)
+    x = torch.randn(n, cin, *hw, generator=g).to(tdt)
+    w = (torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) / math.sqrt(cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x.double(), w, stride=stride, padding=pad)
+    dz = torch.randn(y.shape, generator=g).to(tdt)
+    y.backward(dz.double())
+    got = hip.conv_wgrad(dz.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(), k, stride, pad)
+    assert got.shape == (cout, k * k * cin) and got.dtype == torch.float32
+    assert rel_l2(got.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), w.grad) < 3e-6
+
+
 @pytest.mark.parametrize("n,cin,cout,k,stride,pad,hw", [
     (3, 64, 64, 3, 1, 1, (16, 15)), (2, 64, 128, 3, 2, 1, (41, 37)), (5, 128, 256, 1, 2, 0, (35, 27)), (2, 256, 68, 1, 1, 0, (9, 7)),
     (9, 128, 128, 3, 1, 1, (20, 13)), (1, 192, 64, 3, 2, 1, (11, 14)), (70, 64, 64, 3, 1, 1, (30, 28))])
@@ -506,8 +528,11 @@ def test_training_step_matches_autograd_of_oracle(shape, masked, model):
         dd_ref = sum(float((ref_grads[k] * v[k]).sum()) for k in pick)
         # ReLU / max-pool kinks inside +-eps (measured on this case: 1.1e-2 at 1e-4, 2.7e-4 at 1e-6, 1.7e-8 at 1e-7)
         assert abs(dd_ref - fd) <= 2e-3 * max(abs(fd), 1e-6) + 1e-9, (trial, dd_ref, fd)          # the oracle's own autograd is consistent (a kink inside +-eps now and then: 3.9e-4 seen)
-        dd_err.append(abs(dd_hip - fd) / max(abs(fd), 1e-6))
-        dd_noise.append(abs(sum(float((g32[k].double() * v[k]).sum()) for k in pick) - fd) / max(abs(fd), 1e-6))   # torch's own fp32 autograd
+        # relative to the sum of the per-tensor |<g, v>| rather than to |fd|: the tensors' contributions cancel in some directions (a
+        # direction with a near-zero total measured 12.8 % of |fd| at 1 % of that scale)
+        den = max(sum(abs(float((ref_grads[k] * v[k]).sum())) for k in pick), 1e-6)
+        dd_err.append(abs(dd_hip - fd) / den)
+        dd_noise.append(abs(sum(float((g32[k].double() * v[k]).sum()) for k in pick) - fd) / den)   # torch's own fp32 autograd
     # median 2e-2, worst 6e-2: a run whose ReLU pattern differs from the fp64 oracle's in a late layer moves every upstream gradient
     # coherently (train-mode BatchNorm over 48 samples), and the fp32 sums are not run-to-run identical (atomics): medians of 4e-3 ..
     # 1.4e-2 and worst directions of 2.4e-2 .. 3.5e-2 have been measured on unchanged inputs.  A wrong BatchNorm momentum term or a
