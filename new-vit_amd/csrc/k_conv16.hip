@@ -220,9 +220,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, 
             }
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p8 * 1024), 16, 0, 0);
             r_lane += 8;
-            p_ox += 8;
-            while (p_ox >= g.Wo) { p_ox -= g.Wo; ++p_oy; }
-            while (p_oy >= g.Ho) { p_oy -= g.Ho; ++p_img; }
+            if (g.Ho * g.Wo == 1) {                                   // a plain matrix product (nn.Linear's d weight = dY^T . X): pixel = row
+                p_img += 8;
+            } else {
+                p_ox += 8;
+                while (p_ox >= g.Wo) { p_ox -= g.Wo; ++p_oy; }
+                while (p_oy >= g.Ho) { p_oy -= g.Ho; ++p_img; }
+            }
         }
     };
 
