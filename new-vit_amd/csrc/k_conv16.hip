@@ -329,7 +329,8 @@ int launch_conv_gemm16(const void* x, int dt, int n, int H, int W_, int Cin, int
     MST_CHECK_ARG(cdt == MST_F32 || cdt == dt, "conv_gemm16: output dtype must be f32 or the operand dtype");
     MST_CHECK_ARG(Cin % BK == 0, "conv_gemm16: Cin=%d must be a multiple of %d", Cin, BK);
     MST_CHECK_ARG(Cout > 0 && Cout % 4 == 0, "conv_gemm16: Cout=%d must be a multiple of 4", Cout);
-    MST_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)Wg & 15) == 0 && ((uintptr_t)out & 15) == 0, "conv_gemm16: bases must be 16-byte aligned");
+    MST_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)Wg & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0,
+                  "conv_gemm16: bases (x, Wg, out, bias) must be 16-byte aligned");
     Conv16Geom g{H, W_, Cin, kh, kw, stride, pad, (H + 2 * pad - kh) / stride + 1, (W_ + 2 * pad - kw) / stride + 1, 0};
     MST_CHECK_ARG(g.Ho > 0 && g.Wo > 0 && (int64_t)n * g.Ho * g.Wo < (1ll << 31) - BM, "conv_gemm16: output %d x %d x %d", n, g.Ho, g.Wo);
     const int64_t ldw = (int64_t)kh * kw * Cin;
