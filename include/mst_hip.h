@@ -289,6 +289,10 @@ int mst_cvt16(const float* x, int64_t ldx, int64_t rows, int cols, float scale, 
               int64_t rows_pad, mst_stream_t stream);
 int mst_gemm16_splitk(const void* A, int ab_dtype, int64_t lda, const void* W, int64_t ldw, float* Cpart, int64_t ldc, int64_t M, int N, int K,
                       int splits, int64_t split_stride, mst_stream_t stream);
+/* mst_rope_rows: RoPE of the across-slice attention (rotary_embedding_torch.py:38-62,159-173) in place on packed q | k | v rows [rows, 3 * heads *
+ * head_dim]: the pairs (2p, 2p+1) of q and k rotated by sign * (row % L) * freqs[p]; sign +1 = the training forward, -1 = its adjoint on the
+ * gradient rows (the frequencies carry no gradient: learned_freq = False). */
+int mst_rope_rows(float* qkv, int64_t rows, int L, int heads, int head_dim, const float* freqs, float sign, mst_stream_t stream);
 int mst_gemm_ex(const float* A, const float* B, float* C, int M, int N, int K, const int64_t* strides, int nb1, int nb2,
                 float alpha, float beta, mst_stream_t stream);
 int mst_softmax_rows(float* S, const uint8_t* mask, int64_t rows, int L, int rows_per_batch, mst_stream_t stream);

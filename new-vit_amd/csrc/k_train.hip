@@ -129,6 +129,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// RoPE of the across-slice attention (rotary_embedding_torch.py:38-62,159-173; transformer_blocks.py:262-264) on packed q | k | v rows, in
+// place: the pairs (2p, 2p+1) of every head's q and k are rotated by sign * position * freqs[p] (position = row % L, the class token
+// is position 0).  sign +1: the forward; sign -1: its adjoint on (dq', dk') -- rotations are orthogonal, and the frequencies are buffers
+// without a gradient (learned_freq = False).
+__global__ void rope_rows_kernel(float* __restrict__ qkv, int64_t rows, int L, int heads, int hd, const float* __restrict__ freqs, float sign) {
+    const int half = hd / 2, e = heads * hd;
+    const int64_t total = rows * 2 * heads * half;                     // (row, q|k, head, pair)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % half);
+        const int h = (int)((i / half) % heads);
+        const int which = (int)((i / ((int64_t)half * heads)) % 2);
+        const int64_t r = i / ((int64_t)half * heads * 2);
+        float sn, cs;
+        sincosf(sign * (float)(r % L) * freqs[p], &sn, &cs);
+        float* v = qkv + r * 3 * e + which * e + h * hd + 2 * p;
+        const float a = v[0], b = v[1];
+        v[0] = a * cs - b * sn;
+        v[1] = b * cs + a * sn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // dh = dy * act'(h), in place over dy.  kind 0: GELU (erf form), 1: ReLU.
 __global__ void act_bwd_kernel(const float* __restrict__ h, float* __restrict__ dy, int64_t n, int kind) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -280,6 +302,12 @@ int launch_layernorm_bwd(const float* x, int64_t xs, const float* gamma, const f
     else LNB(32);
 #undef LNB
     return mst_check_launch("layernorm_bwd");
+}
+
+int launch_rope_rows(float* qkv, int64_t rows, int L, int heads, int hd, const float* freqs, float sign, hipStream_t s) {
+    MST_CHECK_ARG(qkv && freqs && rows > 0 && L > 0 && heads > 0 && hd > 0 && hd % 2 == 0, "rope_rows: bad arguments");
+    rope_rows_kernel<<<dim3(grid_for(rows * heads * hd)), dim3(256), 0, s>>>(qkv, rows, L, heads, hd, freqs, sign);
+    return mst_check_launch("rope_rows");
 }
 
 int launch_act_bwd(const float* h, float* dy, int64_t n, int kind, hipStream_t s) {

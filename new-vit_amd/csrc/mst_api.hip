@@ -255,6 +255,9 @@ int mst_conv_wgrad16(const void* dz, const void* x, int dtype, int n, int H, int
                      int nsplit, int64_t rows_per_split, mst_stream_t stream) {
     return launch_conv_wgrad16(dz, x, dtype, n, H, W, Cin, kh, kw, stride, pad, Cout, part, nsplit, rows_per_split, (hipStream_t)stream);
 }
+int mst_rope_rows(float* qkv, int64_t rows, int L, int heads, int head_dim, const float* freqs, float sign, mst_stream_t stream) {
+    return launch_rope_rows(qkv, rows, L, heads, head_dim, freqs, sign, (hipStream_t)stream);
+}
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream) { return launch_cvt32(x, dtype, n, out, (hipStream_t)stream); }
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mst_gemm16_splitk": (_i, [_vp, _i, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i64, _vp]),
     "mst_conv_gemm": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mst_rope_rows": (_i, [_vp, _i64, _i, _i, _i, _vp, _f, _vp]),
     "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
     "mst_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "mst_conv_wgrad16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
@@ -585,6 +586,13 @@ def gemm16_splitk(a: torch.Tensor, w: torch.Tensor, splits: int) -> torch.Tensor
     part = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
     _check(load().mst_gemm16_splitk(ptr(a), dt_of(a), K, ptr(w), K, ptr(part), N, M, N, K, splits, M * N, stream_of(a)), "mst_gemm16_splitk")
     return part
+
+
+def rope_rows(qkv: torch.Tensor, L: int, heads: int, hd: int, freqs: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """mst_rope_rows: rotate the q and k pairs of packed rows [rows, 3*heads*hd] in place (sign -1: the adjoint, for gradient rows)."""
+    _dev(qkv, "rope_rows")
+    _check(load().mst_rope_rows(ptr(qkv), qkv.shape[0], L, heads, hd, ptr(freqs), sign, stream_of(qkv)), "mst_rope_rows")
+    return qkv
 
 
 def softmax_rows(S: torch.Tensor, mask: Optional[torch.Tensor], rows_per_batch: int):

@@ -166,6 +166,14 @@ def fusion_fwd(model, tok: torch.Tensor, B: int, D: int, e: int, hs: int, mask: 
     t = {"xs": xs, "mask": mk}
     t["y1"] = hip.layernorm(xs, lay.norm1.weight.detach(), lay.norm1.bias.detach(), 1e-5)
     t["qkv"] = hip.gemm(t["y1"], lay.self_attn.in_proj_weight.detach(), lay.self_attn.in_proj_bias.detach())
+    rot = getattr(lay.self_attn, "rotary_positional_encoding", None)
+    t["rope"] = None
+    if rot is not None:                                  # RoPE on q and k (transformer_blocks.py:262-264); the rotated rows are what the backward needs
+        if not hasattr(rot, "freqs"):
+            raise NotImplementedError("training step: the LieRE variant of the slice transformer is not on the HIP backward (its rotation "
+                                      "generators are learned: the adjoint of the matrix exponential is not built)")
+        t["rope"] = rot.freqs.detach().to(dev, torch.float32).contiguous()
+        hip.rope_rows(t["qkv"], L, hs, hd, t["rope"], 1.0)
     t["ao"], t["P"] = _attention_fwd(t["qkv"], B, L, hs, hd, 1.0 / math.sqrt(hd), mk)
     xs1 = xs.clone()
     hip.axpby_cols(_lin_fwd(t["ao"], lay.self_attn.out_proj), xs1)
@@ -195,6 +203,8 @@ def fusion_bwd(G: "_Grads", model, t, dfeat: torch.Tensor, B: int, D: int, e: in
     G.ln_bwd(t["xs1"], e, lay.norm2, dy2, e, dxs2, e, dxs1, e, B * L, e, 1e-5)
     dao = G.lin_bwd(dxs1, t["ao"], lay.self_attn.out_proj)
     dqkv = _attention_bwd(dao, t["qkv"], t["P"], B, L, hs, hd, 1.0 / math.sqrt(hd), 1.0)
+    if t["rope"] is not None:
+        hip.rope_rows(dqkv, L, hs, hd, t["rope"], -1.0)    # adjoint of the rotation: gradients of the un-rotated projections
     sa = lay.self_attn
     dW = torch.empty_like(sa.in_proj_weight)
     hip.gemm_ex(dqkv, t["y1"], dW, 3 * e, e, B * L, sa=(1, 3 * e), sb=(e, 1), sc=(e, 1))
@@ -212,8 +222,9 @@ def fusion_bwd(G: "_Grads", model, t, dfeat: torch.Tensor, B: int, D: int, e: in
 
 def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], without_linear: bool):
     import torch.nn as nn
-    if model.rotary is not None:
-        raise NotImplementedError("training step: rotary variants of the slice transformer are not on the HIP backward yet")
+    if model.rotary is not None and model.rotary != "RoPE":
+        raise NotImplementedError("training step: the LieRE variant of the slice transformer is not on the HIP backward (its rotation "
+                                  "generators are learned: the adjoint of the matrix exponential is not built); RoPE is")
     enc = model.encoder
     R = int(enc.num_register_tokens)                     # register tokens (vision_transformer.py:222-230): extra prefix rows without a position
     dev = model.device

@@ -18,9 +18,10 @@ def _oracle_grads(name, kw, seed, src, mask, target, without_linear=False):
     sd = synth.synth_state_dict(kw.get("model_size", "s"), seed, use_bottleneck=kw.get("use_bottleneck", False),
                                 use_slice_pos_emb=kw.get("use_slice_pos_emb", False),
                                 slice_fusion=kw.get("slice_fusion", "transformer"), rotary=kw.get("rotary_positional_encoding"))
-    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    # (RoPE's frequencies are a buffer-like Parameter with requires_grad = False in the reference: rotary_embedding_torch.py learned_freq = False)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("rotary_positional_encoding.freqs")) for k, v in sd.items()}
     out = O.forward(sd, src, model_size=kw.get("model_size", "s"), slice_fusion_type=kw.get("slice_fusion", "transformer"),
-                    src_key_padding_mask=mask, without_linear=without_linear)
+                    src_key_padding_mask=mask, without_linear=without_linear, rotary=kw.get("rotary_positional_encoding"))
     y = out["features"] if without_linear else out["logits"]
     loss = y.square().sum() if without_linear else torch.nn.functional.cross_entropy(y, target)
     loss.backward()
@@ -97,7 +98,7 @@ def test_register_token_encoder_gradients_at_the_stored_grid():
         model(synth.synth_volume((1, 1, 2, 70, 70), 1))
 
 
-@pytest.mark.parametrize("name", ["bottleneck_pos", "average", "linear32"])
+@pytest.mark.parametrize("name", ["bottleneck_pos", "average", "linear32", "rope"])
 def test_fusion_variants_gradients(name):
     g = load_golden(name)
     kw = CASES[name]
@@ -109,6 +110,24 @@ def test_fusion_variants_gradients(name):
     loss = torch.nn.functional.cross_entropy(model(src), target.cuda())
     loss.backward()
     _check_all(model, ref)
+
+
+def test_rope_rotation_is_orthogonal_and_liere_training_raises():
+    """mst_rope_rows: sign -1 undoes sign +1 (the adjoint of a rotation), v is untouched, position 0 (the class token) is the identity;
+    the LieRE variant, whose generators are learned, raises in a training forward."""
+    from mst import hip
+    g = torch.Generator().manual_seed(4)
+    L, heads, hd = 9, 12, 32
+    qkv = torch.randn(3 * L, 3 * heads * hd, generator=g).cuda()
+    fr = (1.0 / (256 ** (torch.arange(0, hd, 2).float() / hd))).cuda()
+    rot = hip.rope_rows(qkv.clone(), L, heads, hd, fr, 1.0)
+    assert torch.equal(rot[:, 2 * heads * hd:], qkv[:, 2 * heads * hd:]) and torch.equal(rot[0::L], qkv[0::L])
+    assert not torch.allclose(rot[1, :heads * hd], qkv[1, :heads * hd])
+    assert float((rot.norm(dim=1) - qkv.norm(dim=1)).abs().max()) < 1e-4
+    assert float((hip.rope_rows(rot.clone(), L, heads, hd, fr, -1.0) - qkv).abs().max()) < 1e-5
+    model = build(CASES["liere"], 1, "fp32").train()
+    with pytest.raises(NotImplementedError, match="LieRE"):
+        model(synth.synth_volume((1, 1, 32, 28, 28), 1))
 
 
 @pytest.mark.parametrize("M,N,K,a_layout,b_layout", [
