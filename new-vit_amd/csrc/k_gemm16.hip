@@ -20,8 +20,10 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+// TN: the N extent of the tile, 128 (default) or 64.  64 halves a workgroup's work and doubles the grid: taken when the 128-wide grid
+// would leave CUs idle (a few thousand token rows against N = 384: 99 workgroups on 256 CUs), wave tile 64 x 32.
 
-template <typename T, int EPI, typename OutT>
+template <typename T, int EPI, typename OutT, int TN = 128>
 __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, int64_t lda,
                                                      const T* __restrict__ W, int64_t ldw,
                                                      const float* __restrict__ bias, OutT* C,
@@ -34,18 +36,20 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
     A += (int64_t)blockIdx.y * K;
     W += (int64_t)blockIdx.y * K;
     C += (int64_t)blockIdx.y * split_stride;
+    constexpr int NI = TN / 32;              // 16-column accumulator blocks per wave (wave tile 64 x TN/2) = W pieces per wave and stage
+    constexpr int W_BYTES = TN * BK * 2;
     char* const As = smem;                   // [2][128][64] T
-    char* const Ws = smem + 2 * TILE_BYTES;  // [2][128][64] T
+    char* const Ws = smem + 2 * TILE_BYTES;  // [2][TN][64] T
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * TN;
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- LDS-DMA source addresses: instruction i of this wave fills tile rows rb*8 .. rb*8+7
     const T* asrc[4];
-    const T* wsrc[4];
+    const T* wsrc[NI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
@@ -53,32 +57,39 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
         int am = m0 + r;
         am = am < M ? am : M - 1;
         asrc[i] = A + (int64_t)am * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = (wave * NI + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
         wsrc[i] = W + (int64_t)(n0 + r) * ldw + c * 8;
     }
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int off = buf * TILE_BYTES + (wave * 4 + i) * 1024;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i]), LDS_PTR(As + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i]), LDS_PTR(Ws + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i]), LDS_PTR(As + buf * TILE_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
             asrc[i] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i]), LDS_PTR(Ws + buf * W_BYTES + (wave * NI + i) * 1024), 16, 0, 0);
             wsrc[i] += BK;
         }
     };
 
     // accumulators start at the bias (no bias load / vmcnt drain left in the epilogue)
-    f32x4 acc[4][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (bias) b0 = *reinterpret_cast<const f32x4*>(bias + n0 + wn * 64 + i * 16 + (lane >> 4) * 4);
+        if (bias) b0 = *reinterpret_cast<const f32x4*>(bias + n0 + wn * (TN / 2) + i * 16 + (lane >> 4) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = b0;
     }
 
     const int sw = (lane >> 1) & 7;  // ((row >> 1) & 7) for row = 16*k + (lane & 15)
     const int a_row_off = (wm * 64 + (lane & 15)) * 128;
-    const int w_row_off = (wn * 64 + (lane & 15)) * 128;
+    const int w_row_off = (wn * (TN / 2) + (lane & 15)) * 128;
 
     const int nk = K / BK;
     stage(0);
@@ -87,19 +98,19 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
         __syncthreads();  // tile t has landed; every wave is done reading the other buffer
         if (t + 1 < nk) stage((t + 1) & 1);
         const char* Ab = As + (t & 1) * TILE_BYTES;
-        const char* Wb = Ws + (t & 1) * TILE_BYTES;
+        const char* Wb = Ws + (t & 1) * W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
-            vec8 af[4], wf[4];
+            vec8 af[4], wf[NI];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 af[j] = *reinterpret_cast<const vec8*>(Ab + a_row_off + j * 16 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
                 wf[i] = *reinterpret_cast<const vec8*>(Wb + w_row_off + i * 16 * 128 + coff);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[i], af[j], acc[i][j]);
         }
@@ -110,8 +121,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * (TN / 2) + i * 16 + (lane >> 4) * 4;
             float4 gv = make_float4(1.f, 1.f, 1.f, 1.f);
             if (EPI == MST_EPI_RESIDUAL && gamma) gv = *reinterpret_cast<const float4*>(gamma + n);
             float sc[4];
@@ -166,10 +177,22 @@ template <typename T, int EPI, typename OutT>
 int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
              int64_t ldc, int64_t M, int N, int K, const float* gamma, float col_scale, int scale_cols,
              hipStream_t s) {
+    const int tiles_m = (int)((M + BM - 1) / BM);
+    static const bool narrow_ok = !(getenv("MST_GEMM16_NARROW") && atoi(getenv("MST_GEMM16_NARROW")) == 0);
+    if (narrow_ok && tiles_m * (N / BN) < 224) {          // the 128-wide grid would leave CUs idle: 128 x 64 tiles, twice the workgroups
+        static mst_lds_once lds_once_n;
+        auto kern = gemm16_kernel<T, EPI, OutT, 64>;
+        constexpr int lds = 2 * TILE_BYTES + 2 * 64 * BK * 2;
+        mst_allow_lds((const void*)kern, lds, &lds_once_n);
+        const int tiles_n = N / 64, nwg = tiles_m * tiles_n;
+        kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
+                                                scale_cols, tiles_n, nwg, 0);
+        return mst_check_launch("gemm16 (128 x 64)");
+    }
     static mst_lds_once lds_once;
     auto kern = gemm16_kernel<T, EPI, OutT>;
     mst_allow_lds((const void*)kern, 4 * TILE_BYTES, &lds_once);
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = N / BN;
+    const int tiles_n = N / BN;
     const int nwg = tiles_m * tiles_n;
     kern<<<dim3(nwg), dim3(256), 4 * TILE_BYTES, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc,
                                                        (int)M, N, K, gamma, col_scale, scale_cols, tiles_n, nwg, 0);
