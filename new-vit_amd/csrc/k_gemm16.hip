@@ -23,7 +23,9 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 // TN: the N extent of the tile, 128 (default) or 64.  64 halves a workgroup's work and doubles the grid: taken when the 128-wide grid
 // would leave CUs idle (a few thousand token rows against N = 384: 99 workgroups on 256 CUs), wave tile 64 x 32.
 
-template <typename T, int EPI, typename OutT, int TN = 128>
+// NS: stages of the LDS ring (2 = double buffer).  The under-filled grids that take TN = 64 run one workgroup per CU, so nothing hides the
+// LDS-DMA latency of a K-step but the ring itself: they use 4 stages (96 KiB) behind a COUNTED vmcnt (the newer stages stay in flight).
+template <typename T, int EPI, typename OutT, int TN = 128, int NS = 2>
 __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, int64_t lda,
                                                      const T* __restrict__ W, int64_t ldw,
                                                      const float* __restrict__ bias, OutT* C,
@@ -38,8 +40,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
     C += (int64_t)blockIdx.y * split_stride;
     constexpr int NI = TN / 32;              // 16-column accumulator blocks per wave (wave tile 64 x TN/2) = W pieces per wave and stage
     constexpr int W_BYTES = TN * BK * 2;
-    char* const As = smem;                   // [2][128][64] T
-    char* const Ws = smem + 2 * TILE_BYTES;  // [2][TN][64] T
+    char* const As = smem;                    // [NS][128][64] T
+    char* const Ws = smem + NS * TILE_BYTES;  // [NS][TN][64] T
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,13 +94,18 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, in
     const int w_row_off = (wn * (TN / 2) + (lane & 15)) * 128;
 
     const int nk = K / BK;
-    stage(0);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) stage(p);
     for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile t has landed; every wave is done reading the other buffer
-        if (t + 1 < nk) stage((t + 1) & 1);
-        const char* Ab = As + (t & 1) * TILE_BYTES;
-        const char* Wb = Ws + (t & 1) * W_BYTES;
+        // stage t has landed once at most the NS - 2 stages behind it are outstanding (LDS-DMA completes in issue order); near the
+        // end fewer are in flight: wait for everything
+        if (NS > 2 && t + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (4 + NI)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage t is visible to every wave; every wave is done reading the buffer the next stage overwrites
+        if (t + NS - 1 < nk) stage((t + NS - 1) % NS);
+        const char* Ab = As + (t % NS) * TILE_BYTES;
+        const char* Wb = Ws + (t % NS) * W_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
@@ -180,13 +187,22 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     const int tiles_m = (int)((M + BM - 1) / BM);
     static const bool narrow_ok = !(getenv("MST_GEMM16_NARROW") && atoi(getenv("MST_GEMM16_NARROW")) == 0);
     if (narrow_ok && tiles_m * (N / BN) < 224) {          // the 128-wide grid would leave CUs idle: 128 x 64 tiles, twice the workgroups
-        static mst_lds_once lds_once_n;
-        auto kern = gemm16_kernel<T, EPI, OutT, 64>;
-        constexpr int lds = 2 * TILE_BYTES + 2 * 64 * BK * 2;
-        mst_allow_lds((const void*)kern, lds, &lds_once_n);
         const int tiles_n = N / 64, nwg = tiles_m * tiles_n;
-        kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
-                                                scale_cols, tiles_n, nwg, 0);
+        if (nwg <= 256) {                                // one workgroup per CU at most: only a deeper ring hides the LDS-DMA latency
+            static mst_lds_once lds_once_n4;
+            auto kern = gemm16_kernel<T, EPI, OutT, 64, 4>;
+            constexpr int lds = 4 * TILE_BYTES + 4 * 64 * BK * 2;
+            mst_allow_lds((const void*)kern, lds, &lds_once_n4);
+            kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
+                                                    scale_cols, tiles_n, nwg, 0);
+        } else {                                         // several workgroups per CU cover each other (a 96 KiB ring would allow one)
+            static mst_lds_once lds_once_n;
+            auto kern = gemm16_kernel<T, EPI, OutT, 64, 2>;
+            constexpr int lds = 2 * TILE_BYTES + 2 * 64 * BK * 2;
+            mst_allow_lds((const void*)kern, lds, &lds_once_n);
+            kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
+                                                    scale_cols, tiles_n, nwg, 0);
+        }
         return mst_check_launch("gemm16 (128 x 64)");
     }
     static mst_lds_once lds_once;
