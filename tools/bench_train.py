@@ -25,6 +25,56 @@ def timed(fn, n, warm=2):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def backward_rooflines():
+    """`roofline` lines for the dominant BACKWARD kernels of the two training steps: algorithmic FLOPs of one launch
+    / its HIP-event time against the dense MFMA peak of the operand type (bf16 / fp16 2.5 PF, fp32 MFMA 157 TF at the nominal clock)."""
+    from mst import hip
+
+    def ev(fn, n=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    def line(case, kernel, flops, ms, peak_tf, dtype):
+        tf = flops / ms / 1e9
+        print(json.dumps({"case": case, "roofline": {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 1), "peak": peak_tf, "unit": "TFLOP/s",
+                                                     "frac": round(tf / peak_tf, 3), "flops_per_launch": flops, "avg_launch_ms": round(ms, 4), "dtype": dtype}}),
+              flush=True)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    # (1) MST-DINOv2 mixed step, 2 x 32 x 224^2 = 16,448 tokens: d weight of fc1 (N 1536, K 384), the largest of the four per block
+    M, N, K = 16448, 1536, 384
+    dY, X = torch.randn(M, N, device="cuda", generator=g), torch.randn(M, K, device="cuda", generator=g)
+    for dt, nm in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
+        d16, x16 = hip.cvt16(dY, dt), hip.cvt16(X, dt)
+        sp, kc = 14, 1216
+        at, xt = hip.cvt16(dY, dt, transpose=True, rows_pad=sp * kc), hip.cvt16(X, dt, transpose=True, rows_pad=sp * kc)
+        line("DINOv2 mixed step 2x32x224^2: d weight fc1 = dY^T . X (transposed images, split-K 128x128x64 GEMM)", "gemm16_kernel (split-K)", 2.0 * M * N * K,
+             ev(lambda: hip.gemm16_splitk(at, xt, sp)), 2500.0, nm)
+        line("same product through the transposing-read kernel", "wgrad16_kernel", 2.0 * M * N * K, ev(lambda: hip.conv_wgrad(d16, x16.view(M, 1, 1, K), 1, 1, 0)), 2500.0, nm)
+        w16 = hip.cvt16(torch.randn(N, K, device="cuda", generator=g), dt, transpose=True)
+        line("DINOv2 mixed step: d input of fc1 = dY . W", "gemm16 family", 2.0 * M * N * K, ev(lambda: hip.gemm(d16, w16, None, out_dtype=torch.float32)), 2500.0, nm)
+    dW = torch.empty(N, K, device="cuda")
+    line("DINOv2 fp32 step: d weight fc1 (strided fp32 MFMA GEMM, 16 slabs)", "gemm_ex_kernel<2,2>", 2.0 * M * N * K,
+         ev(lambda: hip.gemm_ex(dY, X, torch.empty(16, N * K, device="cuda"), N, K, M // 16, sa=(1, N), sb=(K, 1), sc=(K, 1), nb=(16, 1), ba=(M // 16 * N, 0),
+                                bb=(M // 16 * K, 0), bc=(N * K, 0))), 157.0, "fp32")
+    # (2) ResNet-34 step at the configs[3] per-GPU shape (128 images of 512^2): the layer-1 3x3 convolution (64 -> 64 channels at 128 x 128)
+    n, H, C, k = 128, 128, 64, 3
+    x = torch.randn(n, H, H, C, device="cuda", generator=g)
+    dz = torch.randn(n * H * H, C, device="cuda", generator=g)
+    fl = 2.0 * n * H * H * C * C * k * k
+    line("ResNet-34 fp32 step 128x512^2: d weight of a layer-1 convolution (implicit GEMM)", "wgrad32_kernel", fl, ev(lambda: hip.conv_wgrad(dz, x, k, 1, 1), 5), 157.0, "fp32")
+    x16, dz16 = hip.cvt16(x.view(-1, C), torch.bfloat16).view(x.shape), hip.cvt16(dz, torch.bfloat16)
+    line("ResNet-34 mixed step: the same d weight on bf16 operands (transposing LDS reads)", "wgrad16_kernel", fl, ev(lambda: hip.conv_wgrad(dz16, x16, k, 1, 1), 5), 2500.0, "bf16")
+    wt = torch.randn(C, k * k * C, device="cuda", generator=g).to(torch.bfloat16)
+    line("ResNet-34 mixed step: d input of that convolution (implicit GEMM, gathered LDS-DMA)", "conv16_kernel", fl, ev(lambda: hip.conv_dgrad(dz16.view(n, H, H, C), wt, k, 1, 1, H, H), 5), 2500.0, "bf16")
+
+
 def train_case(name, model, shape, n=5):
     model = model.cuda().train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
@@ -50,6 +100,9 @@ def train_case(name, model, shape, n=5):
 
 
 def main():
+    if "--rooflines" in sys.argv:
+        backward_rooflines()
+        return
     dino_shapes = ((1, 1, 16, 224, 224),) if "--only-dino-c1" in sys.argv else ((2, 1, 32, 224, 224),) if "--only-dino-2x32" in sys.argv else ((1, 1, 16, 224, 224), (2, 1, 32, 224, 224))
     for shape in (() if "--only-resnet" in sys.argv else dino_shapes):
         for prec in (("fp32", "bf16", "fp16") if "--mixed" in sys.argv else ("fp16",) if "--fp16" in sys.argv else ("fp32",)):
