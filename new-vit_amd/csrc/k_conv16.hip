@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(const T* __restrict__ x, Co
 // form).  Both operands are stored pixel-major ([r][co], [pixel][c]) but the MFMA wants 8 consecutive K values (pixels) per lane: the tiles
 // land in LDS as they are (64 pixels x 64 columns images, LDS-DMA, the x rows gathered per tap with the zero page for padding) and the
 // fragments are read with the hardware transpose (ds_read_b64_tr_b16), the way the attention kernel reads V^T (k_attn16.hip): the same
-// lane map on both operands permutes K identically, so the sum is unchanged.  128 x 128 output tile per workgroup (4 waves x 64 x 64,
-// v_mfma_f32_32x32x16), K-step 64 pixels, LDS double buffer; pixels split over blockIdx.z into fp32 partial products.
+// lane map on both operands permutes K identically, so the sum is unchanged.  128 x 128 (or 64 x 128) output tile per workgroup, 4 waves x
+// 64 x 64 accumulators of v_mfma_f32_32x32x16, K-step 64 pixels, three-stage LDS ring; pixels split over blockIdx.z into fp32 partial products.
 struct Wgrad16Args {
     int Cout, Kc, H, W, Cin, kw, stride, pad, Ho, Wo;
     int64_t rows, rows_per_split;
@@ -170,30 +170,41 @@ __device__ __forceinline__ typename V8<T>::type tr_frag(const char* p) {       /
     return u.v;
 }
 
-template <typename T>
+// MI = 2: 128 x 128 output tile (two dz images: wave (wm, wn) multiplies dz image wm with x image wn over the whole stage).
+// MI = 1: 64 x 128 tile for Cout <= 64 (the 64-channel stage, where the second dz image would be padding): one dz image, the waves wm = 0 / 1
+//         take the first / second 32 pixels of each stage and their accumulators are added through LDS at the end.
+// NS = 2: double buffer (64 / 48 KiB: two or three workgroups per CU cover each other's LDS-DMA latency).  NS = 3 behind a counted vmcnt was
+// measured SLOWER on the 128-row tile (0.094 -> 0.117 ms on the DINOv2 fc1 shape: one workgroup per CU at 96 KiB; the kernel is bound by
+// its LDS reads and address arithmetic, not by the latency), so 2 is what runs.
+template <typename T, int MI, int NS = 2>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, const T* __restrict__ x, float* __restrict__ part, Wgrad16Args g) {
     typedef typename V8<T>::type vec8;
     constexpr int IMG = 64 * 128;                                     // one image: 64 pixels x 64 columns x 2 B
-    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * IMG];   // [buf][A sub 0, A sub 1, B sub 0, B sub 1]
+    constexpr int NIMG = MI + 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [NS][dz images 0 .. MI-1, x image 0, x image 1]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * (64 * MI), n0 = blockIdx.x * 128;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t r_begin = (int64_t)blockIdx.z * g.rows_per_split;
     const int64_t r_end = r_begin + g.rows_per_split < g.rows ? r_begin + g.rows_per_split : g.rows;
 
-    // ---- staging: wave w fills image w of a stage (0, 1: dz columns m0 + 64 w ..; 2, 3: x columns of (tap, c) n0 + 64 (w - 2) ..), eight
-    // 1 KiB pieces of 8 pixels each; lane -> pixel row (lane >> 3) of the piece, LDS slot lane & 7, source chunk permuted like the V image
-    const bool is_b = wave >= 2;
-    const int sub = wave & 1;
+    // ---- staging: one image per loader wave and stage (MI = 2: waves 0, 1 the dz images, 2, 3 the x images; MI = 1: wave 0 dz, 1, 2 x, wave
+    // 3 loads nothing), eight 1 KiB pieces of 8 pixels; lane -> pixel row (lane >> 3) of the piece, LDS slot lane & 7, source chunk
+    // permuted like the V image of k_attn16.hip (the permutation depends on bit 1 of the row only: constant per lane)
+    const int my_img = wave;                                          // image index inside a stage
+    const bool loader = my_img < NIMG;
+    const bool is_b = my_img >= MI;
+    const int sub = is_b ? my_img - MI : my_img;
     const int col0 = is_b ? n0 + 64 * sub : m0 + 64 * sub;            // first column of this image
-    const bool img_ok = is_b ? col0 < g.Kc : col0 < g.Cout;           // the last tile's second image may lie beyond the matrix
+    const bool img_ok = loader && (is_b ? col0 < g.Kc : col0 < g.Cout);
     const int tap = is_b ? col0 / g.Cin : 0, c0 = is_b ? col0 - tap * g.Cin : col0;
     const int ky = tap / g.kw, kx = tap - ky * g.kw;
     const int prow = lane >> 3;
-    // pixel walk of the B loader: (img, oy, ox) of pixel r_begin + prow, advanced by 8 pixels per piece
+    const int chunk = (lane & 7) ^ (((prow >> 1) & 1) << 2);
     int64_t r_lane = r_begin + prow;
-    int p_img, p_oy, p_ox;
+    const T* a_ptr = dz + r_lane * g.Cout + c0 + chunk * 8;           // dz loader: + 8 rows per piece
+    int p_img, p_oy, p_ox;                                            // x loader: (image, oy, ox) of pixel r_lane, advanced by 8 pixels per piece
     {
         const int hw = g.Ho * g.Wo;
         p_img = (int)(r_lane / hw);
@@ -201,31 +212,33 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, 
         p_oy = rem / g.Wo;
         p_ox = rem - p_oy * g.Wo;
     }
+    const int64_t img_elems = (int64_t)g.H * g.W * g.Cin;             // < 2^31 (launcher): per-image offsets fit 32 bits
+    const T* x_img = x + p_img * img_elems + c0 + chunk * 8;
+    const bool plain = g.Ho * g.Wo == 1;                              // nn.Linear's d weight: pixel = row, no window
     const char* const zsrc = conv16_zero_page + ((lane & 7) << 4);
-    auto stage = [&](int buf) {
-        char* dst = smem + (buf * 4 + wave) * IMG;
+    auto stage = [&](int st) {
+        if (!loader) return;
+        char* dst = smem + (st * NIMG + my_img) * IMG;
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) {
-            const int row = p8 * 8 + prow;
-            const int chunk = (lane & 7) ^ (((row >> 1) & 1) << 2);
             const char* src = zsrc;
             if (img_ok && r_lane < r_end) {
                 if (!is_b) {
-                    src = reinterpret_cast<const char*>(dz + r_lane * g.Cout + c0 + chunk * 8);
+                    src = reinterpret_cast<const char*>(a_ptr);
                 } else {
                     const int iy = p_oy * g.stride - g.pad + ky, ix = p_ox * g.stride - g.pad + kx;
-                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                        src = reinterpret_cast<const char*>(x + (((int64_t)p_img * g.H + iy) * g.W + ix) * g.Cin + c0 + chunk * 8);
+                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) src = reinterpret_cast<const char*>(x_img + (iy * g.W + ix) * g.Cin);
                 }
             }
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + p8 * 1024), 16, 0, 0);
             r_lane += 8;
-            if (g.Ho * g.Wo == 1) {                                   // a plain matrix product (nn.Linear's d weight = dY^T . X): pixel = row
-                p_img += 8;
+            a_ptr += 8 * (int64_t)g.Cout;
+            if (plain) {
+                x_img += 8 * img_elems;
             } else {
                 p_ox += 8;
                 while (p_ox >= g.Wo) { p_ox -= g.Wo; ++p_oy; }
-                while (p_oy >= g.Ho) { p_oy -= g.Ho; ++p_img; }
+                while (p_oy >= g.Ho) { p_oy -= g.Ho; x_img += img_elems; }
             }
         }
     };
@@ -248,16 +261,21 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int64_t nst = (r_end - r_begin + 63) / 64;
     stage(0);
-    int buf = 0;
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                              // this stage has landed; every wave is done reading the other buffer
-        if (r0 + 64 < r_end) stage(buf ^ 1);
-        const char* Ai = smem + (buf * 4 + wm) * IMG;
-        const char* Bi = smem + (buf * 4 + 2 + wn) * IMG;
+    if (NS == 3 && nst > 1) stage(1);
+    for (int64_t t = 0; t < nst; ++t) {
+        // NS = 3: stage t has landed once only the stage behind it is outstanding (8 pieces of this wave; LDS-DMA completes in issue order)
+        if (NS == 3 && t + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                              // stage t is visible; every wave is done reading the buffer the next issue overwrites
+        if (t + NS - 1 < nst) stage((int)((t + NS - 1) % NS));
+        const int st = (int)(t % NS);
+        const char* Ai = smem + (st * NIMG + (MI == 2 ? wm : 0)) * IMG;
+        const char* Bi = smem + (st * NIMG + MI + wn) * IMG;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int kq = 0; kq < (MI == 2 ? 4 : 2); ++kq) {
+            const int ks = MI == 2 ? kq : 2 * wm + kq;                // MI = 1: this wave's half of the stage's pixels
             vec8 af[2], bf[2];
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -269,9 +287,30 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
-        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (an empty split issued its first stage and never waited for it)
+    if (MI == 1) {                                                    // the two pixel halves meet: waves 2, 3 hand their sums to waves 0, 1
+        __syncthreads();                                              // the ring is free
+        float* ex = reinterpret_cast<float*>(smem) + (wn * 64 + lane) * 65;      // 64 floats per lane (+1: bank spread), per x image
+        if (wm == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[(i * 2 + j) * 16 + r] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wm == 1) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[(i * 2 + j) * 16 + r];
     }
     float* C = part + (int64_t)blockIdx.z * g.Cout * g.Kc;
+    const int mrow0 = m0 + (MI == 2 ? wm * 64 : 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -280,7 +319,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const T* __restrict__ dz, 
             if (col >= g.Kc) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.Cout) C[(int64_t)row * g.Kc + col] = acc[i][j][r];
             }
         }
@@ -374,9 +413,22 @@ int launch_conv_wgrad16(const void* dz, const void* x, int dt, int n, int H, int
     const int64_t rows = (int64_t)n * Ho * Wo;
     MST_CHECK_ARG(Ho > 0 && Wo > 0 && nsplit > 0 && nsplit <= 65535 && rows_per_split > 0 && rows_per_split % 64 == 0 && (int64_t)nsplit * rows_per_split >= rows,
                   "conv_wgrad16: %d splits of %lld rows (a multiple of 64) do not cover %lld", nsplit, (long long)rows_per_split, (long long)rows);
+    MST_CHECK_ARG((int64_t)H * W_ * Cin < (1ll << 31), "conv_wgrad16: one image of %d x %d x %d elements exceeds 32-bit offsets", H, W_, Cin);
     Wgrad16Args g{Cout, kh * kw * Cin, H, W_, Cin, kw, stride, pad, Ho, Wo, rows, rows_per_split};
-    const dim3 grid((g.Kc + 127) / 128, (Cout + 127) / 128, nsplit);
-    if (dt == MST_BF16) wgrad16_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const bf16_t*)dz, (const bf16_t*)x, part, g);
-    else wgrad16_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const f16_t*)dz, (const f16_t*)x, part, g);
+    constexpr int IMG = 64 * 128;
+#define WG16(T, MI)                                                                                                        \
+    {                                                                                                                      \
+        static mst_lds_once once;                                                                                          \
+        auto kern = wgrad16_kernel<T, MI>;                                                                                 \
+        constexpr int lds = 2 * (MI + 2) * IMG;                                                                            \
+        mst_allow_lds((const void*)kern, lds, &once);                                                                      \
+        kern<<<dim3((g.Kc + 127) / 128, (Cout + 64 * MI - 1) / (64 * MI), nsplit), dim3(256), lds, s>>>((const T*)dz, (const T*)x, part, g); \
+    }
+    if (Cout <= 64) {
+        if (dt == MST_BF16) WG16(bf16_t, 1) else WG16(f16_t, 1)
+    } else {
+        if (dt == MST_BF16) WG16(bf16_t, 2) else WG16(f16_t, 2)
+    }
+#undef WG16
     return mst_check_launch("conv_wgrad16");
 }
