@@ -23,8 +23,8 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 // TN: the N extent of the tile, 128 (default) or 64.  64 halves a workgroup's work and doubles the grid: taken when the 128-wide grid
 // would leave CUs idle (a few thousand token rows against N = 384: 99 workgroups on 256 CUs), wave tile 64 x 32.
 
-// NS: stages of the LDS ring (2 = double buffer).  The under-filled grids that take TN = 64 run one workgroup per CU, so nothing hides the
-// LDS-DMA latency of a K-step but the ring itself: they use 4 stages (96 KiB) behind a COUNTED vmcnt (the newer stages stay in flight).
+// NS: stages of the LDS ring (2 = double buffer, what every launch uses).  A 4-stage ring behind a COUNTED vmcnt (the newer stages stay in
+// flight) for the one-workgroup-per-CU grids of TN = 64 was measured: 0.994 vs 0.992 ms per 16 x 224^2 forward -- no gain, not dispatched.
 template <typename T, int EPI, typename OutT, int TN = 128, int NS = 2>
 __global__ __launch_bounds__(256) void gemm16_kernel(const T* __restrict__ A, int64_t lda,
                                                      const T* __restrict__ W, int64_t ldw,
@@ -188,21 +188,12 @@ int launch_t(const void* A, int64_t lda, const void* W, int64_t ldw, const float
     static const bool narrow_ok = !(getenv("MST_GEMM16_NARROW") && atoi(getenv("MST_GEMM16_NARROW")) == 0);
     if (narrow_ok && tiles_m * (N / BN) < 224) {          // the 128-wide grid would leave CUs idle: 128 x 64 tiles, twice the workgroups
         const int tiles_n = N / 64, nwg = tiles_m * tiles_n;
-        if (nwg <= 256) {                                // one workgroup per CU at most: only a deeper ring hides the LDS-DMA latency
-            static mst_lds_once lds_once_n4;
-            auto kern = gemm16_kernel<T, EPI, OutT, 64, 4>;
-            constexpr int lds = 4 * TILE_BYTES + 4 * 64 * BK * 2;
-            mst_allow_lds((const void*)kern, lds, &lds_once_n4);
-            kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
-                                                    scale_cols, tiles_n, nwg, 0);
-        } else {                                         // several workgroups per CU cover each other (a 96 KiB ring would allow one)
-            static mst_lds_once lds_once_n;
-            auto kern = gemm16_kernel<T, EPI, OutT, 64, 2>;
-            constexpr int lds = 2 * TILE_BYTES + 2 * 64 * BK * 2;
-            mst_allow_lds((const void*)kern, lds, &lds_once_n);
-            kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
-                                                    scale_cols, tiles_n, nwg, 0);
-        }
+        static mst_lds_once lds_once_n;
+        auto kern = gemm16_kernel<T, EPI, OutT, 64, 2>;
+        constexpr int lds = 2 * TILE_BYTES + 2 * 64 * BK * 2;
+        mst_allow_lds((const void*)kern, lds, &lds_once_n);
+        kern<<<dim3(nwg), dim3(256), lds, s>>>((const T*)A, lda, (const T*)W, ldw, bias, (OutT*)C, ldc, (int)M, N, K, gamma, col_scale,
+                                                scale_cols, tiles_n, nwg, 0);
         return mst_check_launch("gemm16 (128 x 64)");
     }
     static mst_lds_once lds_once;
