@@ -149,6 +149,11 @@ int mst_conv_gemm(const float* x, int n, int H, int W, int Cin, int kh, int kw, 
 int mst_conv_gemm16(const void* x, int dtype, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
                     void* out, int out_dtype, int Cout, int epilogue, mst_stream_t stream);
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream);
+/* The stem of the 16-bit backbone: mst_im2col_nhwc with the rows rounded to out_dtype (bf16 / f16) on the way out, and mst_maxpool_nhwc on
+ * 16-bit activations (3 x 3, stride 2, padding 1). */
+int mst_im2col_nhwc16(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, void* col, int out_dtype,
+                      mst_stream_t stream);
+int mst_maxpool_nhwc16(const void* x, int dtype, int n, int H, int W, int C, void* y, mst_stream_t stream);
 /* mst_conv_dgrad: d input of a convolution AS a convolution (what torch.autograd's conv backward gives the reference): the same implicit GEMMs
  * with stride 1, padding k - 1 - pad and the gradient rows dilated by the forward stride (1 or 2), instead of dZ . W into a [rows, kh*kw*Cin]
  * matrix and a scatter with atomics (mst_col2im_nhwc).  dz [n,Ho,Wo,Cout] and Wt [Cin, kh*kw*Cout] of `dtype` (f32: Cout % 16 == 0; bf16 / f16:

@@ -9,8 +9,9 @@
 
 namespace {
 
+template <typename OutT>
 __global__ void im2col_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, int kh, int kw, int stride, int pad, int Ho,
-                                   int Wo, int K, int Kpad, int64_t rows, float* __restrict__ col) {
+                                   int Wo, int K, int Kpad, int64_t rows, OutT* __restrict__ col) {
     const int64_t total = rows * Kpad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / Kpad;
@@ -23,12 +24,13 @@ __global__ void im2col_nhwc_kernel(const float* __restrict__ x, int H, int W, in
             const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * H + iy) * W + ix) * C + c];
         }
-        col[i] = v;
+        col[i] = (OutT)v;
     }
 }
 
-__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, int H, int W, int C, int Ho, int Wo, int64_t total,
-                                    float* __restrict__ y) {
+template <typename T>
+__global__ void maxpool_nhwc_kernel(const T* __restrict__ x, int H, int W, int C, int Ho, int Wo, int64_t total,
+                                    T* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int ox = (int)((i / C) % Wo), oy = (int)((i / ((int64_t)C * Wo)) % Ho);
@@ -40,10 +42,10 @@ __global__ void maxpool_nhwc_kernel(const float* __restrict__ x, int H, int W, i
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= W) continue;
-                m = fmaxf(m, x[((n * H + iy) * W + ix) * C + c]);
+                m = fmaxf(m, (float)x[((n * H + iy) * W + ix) * C + c]);
             }
         }
-        y[i] = m;
+        y[i] = (T)m;
     }
 }
 
@@ -222,14 +224,35 @@ int launch_im2col_nhwc(const float* x, int n, int H, int W, int C, int kh, int k
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1, K = kh * kw * C;
     MST_CHECK_ARG(Ho > 0 && Wo > 0 && Kpad >= K, "im2col: bad geometry (Ho=%d Wo=%d K=%d Kpad=%d)", Ho, Wo, K, Kpad);
     const int64_t rows = (int64_t)n * Ho * Wo;
-    im2col_nhwc_kernel<<<dim3(cgrid(rows * Kpad)), dim3(256), 0, s>>>(x, H, W, C, kh, kw, stride, pad, Ho, Wo, K, Kpad, rows, col);
+    im2col_nhwc_kernel<float><<<dim3(cgrid(rows * Kpad)), dim3(256), 0, s>>>(x, H, W, C, kh, kw, stride, pad, Ho, Wo, K, Kpad, rows, col);
     return mst_check_launch("im2col_nhwc");
+}
+
+// the same rows rounded to a 16-bit type on the way out (the stem of the 16-bit inference backbone: its im2col rows are the "pixels" of a
+// 1 x 1 mst_conv_gemm16) and the 3 x 3 / 2 max pool on 16-bit activations
+int launch_im2col_nhwc16(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, void* col, int dt, hipStream_t s) {
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1, K = kh * kw * C;
+    MST_CHECK_ARG(Ho > 0 && Wo > 0 && Kpad >= K, "im2col16: bad geometry (Ho=%d Wo=%d K=%d Kpad=%d)", Ho, Wo, K, Kpad);
+    const int64_t rows = (int64_t)n * Ho * Wo;
+    if (dt == MST_BF16) im2col_nhwc_kernel<bf16_t><<<dim3(cgrid(rows * Kpad)), dim3(256), 0, s>>>(x, H, W, C, kh, kw, stride, pad, Ho, Wo, K, Kpad, rows, (bf16_t*)col);
+    else if (dt == MST_F16) im2col_nhwc_kernel<f16_t><<<dim3(cgrid(rows * Kpad)), dim3(256), 0, s>>>(x, H, W, C, kh, kw, stride, pad, Ho, Wo, K, Kpad, rows, (f16_t*)col);
+    else { mst_set_error("im2col16: output dtype %d (bf16 / f16)", dt); return MST_EINVAL; }
+    return mst_check_launch("im2col_nhwc16");
+}
+
+int launch_maxpool_nhwc16(const void* x, int dt, int n, int H, int W, int C, void* y, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)n * Ho * Wo * C;
+    if (dt == MST_BF16) maxpool_nhwc_kernel<bf16_t><<<dim3(cgrid(total)), dim3(256), 0, s>>>((const bf16_t*)x, H, W, C, Ho, Wo, total, (bf16_t*)y);
+    else if (dt == MST_F16) maxpool_nhwc_kernel<f16_t><<<dim3(cgrid(total)), dim3(256), 0, s>>>((const f16_t*)x, H, W, C, Ho, Wo, total, (f16_t*)y);
+    else { mst_set_error("maxpool16: dtype %d (bf16 / f16)", dt); return MST_EINVAL; }
+    return mst_check_launch("maxpool_nhwc16");
 }
 
 int launch_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, hipStream_t s) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)n * Ho * Wo * C;
-    maxpool_nhwc_kernel<<<dim3(cgrid(total)), dim3(256), 0, s>>>(x, H, W, C, Ho, Wo, total, y);
+    maxpool_nhwc_kernel<float><<<dim3(cgrid(total)), dim3(256), 0, s>>>(x, H, W, C, Ho, Wo, total, y);
     return mst_check_launch("maxpool_nhwc");
 }
 

@@ -258,6 +258,15 @@ int mst_conv_wgrad16(const void* dz, const void* x, int dtype, int n, int H, int
 int mst_rope_rows(float* qkv, int64_t rows, int L, int heads, int head_dim, const float* freqs, float sign, mst_stream_t stream) {
     return launch_rope_rows(qkv, rows, L, heads, head_dim, freqs, sign, (hipStream_t)stream);
 }
+int mst_im2col_nhwc16(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, void* col, int out_dtype,
+                      mst_stream_t stream) {
+    MST_CHECK_ARG(x && col && n > 0, "im2col16: bad arguments");
+    return launch_im2col_nhwc16(x, n, H, W, C, kh, kw, stride, pad, Kpad, col, out_dtype, (hipStream_t)stream);
+}
+int mst_maxpool_nhwc16(const void* x, int dtype, int n, int H, int W, int C, void* y, mst_stream_t stream) {
+    MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool16: bad arguments");
+    return launch_maxpool_nhwc16(x, dtype, n, H, W, C, y, (hipStream_t)stream);
+}
 int mst_cvt32(const void* x, int dtype, int64_t n, float* out, mst_stream_t stream) { return launch_cvt32(x, dtype, n, out, (hipStream_t)stream); }
 int mst_maxpool_nhwc(const float* x, int n, int H, int W, int C, float* y, mst_stream_t stream) {
     MST_CHECK_ARG(x && y && n > 0 && H > 0 && W > 0 && C > 0, "maxpool_nhwc: bad arguments");

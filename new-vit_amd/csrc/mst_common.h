@@ -179,6 +179,8 @@ int launch_conv_wgrad32(const float* dz, const float* x, int n, int H, int W, in
 int launch_conv_wgrad16(const void* dz, const void* x, int dt, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, int Cout, float* part,
                         int nsplit, int64_t rows_per_split, hipStream_t s);
 int launch_rope_rows(float* qkv, int64_t rows, int L, int heads, int hd, const float* freqs, float sign, hipStream_t s);
+int launch_im2col_nhwc16(const float* x, int n, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, void* col, int dt, hipStream_t s);
+int launch_maxpool_nhwc16(const void* x, int dt, int n, int H, int W, int C, void* y, hipStream_t s);
 int launch_cvt32(const void* x, int dt, int64_t n, float* out, hipStream_t s);
 int launch_conv_gemm16(const void* x, int dt, int n, int H, int W, int Cin, int kh, int kw, int stride, int pad, const void* Wg, const float* bias,
                        void* out, int cdt, int Cout, int epi, hipStream_t s);

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mst_conv_gemm16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mst_rope_rows": (_i, [_vp, _i64, _i, _i, _i, _vp, _f, _vp]),
     "mst_cvt32": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "mst_im2col_nhwc16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mst_maxpool_nhwc16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mst_conv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "mst_conv_wgrad16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i64, _vp]),
     "mst_conv_dgrad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
@@ -661,15 +663,19 @@ def pos_embed_interp_bwd(dout: torch.Tensor, M: int, gh: int, gw: int, offset: f
 
 
 # ---- convolutional backbone ops (NHWC fp32) --------------------------------------------------------------------------
-def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, kpad: Optional[int] = None) -> torch.Tensor:
-    """x [n,H,W,C] fp32 -> col [n*Ho*Wo, Kpad] (K = kh*kw*C in (ky,kx,c) order, zero-padded to Kpad)."""
+def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, kpad: Optional[int] = None,
+                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """x [n,H,W,C] fp32 -> col [n*Ho*Wo, Kpad] (K = kh*kw*C in (ky,kx,c) order, zero-padded to Kpad), fp32 or rounded to bf16 / fp16."""
     _dev(x, "im2col_nhwc")
     n, H, W, Cc = x.shape
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     K = kh * kw * Cc
     kpad = kpad or (K + 15) // 16 * 16
-    col = torch.empty((n * Ho * Wo, kpad), dtype=torch.float32, device=x.device)
-    _check(load().mst_im2col_nhwc(ptr(x), n, H, W, Cc, kh, kw, stride, pad, kpad, ptr(col), stream_of(x)), "mst_im2col_nhwc")
+    col = torch.empty((n * Ho * Wo, kpad), dtype=out_dtype, device=x.device)
+    if out_dtype == torch.float32:
+        _check(load().mst_im2col_nhwc(ptr(x), n, H, W, Cc, kh, kw, stride, pad, kpad, ptr(col), stream_of(x)), "mst_im2col_nhwc")
+    else:
+        _check(load().mst_im2col_nhwc16(ptr(x), n, H, W, Cc, kh, kw, stride, pad, kpad, ptr(col), dt_of(col), stream_of(x)), "mst_im2col_nhwc16")
     return col
 
 
@@ -766,8 +772,11 @@ def cvt32(x: torch.Tensor) -> torch.Tensor:
 def maxpool_nhwc(x: torch.Tensor) -> torch.Tensor:
     _dev(x, "maxpool_nhwc")
     n, H, W, Cc = x.shape
-    y = torch.empty((n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
-    _check(load().mst_maxpool_nhwc(ptr(x), n, H, W, Cc, ptr(y), stream_of(x)), "mst_maxpool_nhwc")
+    y = torch.empty((n, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.float32:
+        _check(load().mst_maxpool_nhwc(ptr(x), n, H, W, Cc, ptr(y), stream_of(x)), "mst_maxpool_nhwc")
+    else:
+        _check(load().mst_maxpool_nhwc16(ptr(x), dt_of(x), n, H, W, Cc, ptr(y), stream_of(x)), "mst_maxpool_nhwc16")
     return y
 
 

@@ -251,13 +251,12 @@ class ResNet(BasicClassifier):
                 y = hip.gemm(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), w, b, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, 64)
                 y = hip.maxpool_nhwc(y)
             else:
-                # the stem's 49 taps of ONE input channel are no multiple of 64 channels: its im2col rows (padded to 64) are the "pixels" of a
-                # 1 x 1 convolution; the max pool stays fp32, the activations behind it are 16-bit
-                col = hip.cvt16(hip.im2col_nhwc(x, 7, 7, 2, 3, kpad), p["dtype"]).view(n, Ho, Wo, kpad)
-                y = hip.conv_gemm16(col, w, b, 1, 1, 1, 0, epilogue=hip.EPI_BIAS_RELU, out_dtype=torch.float32).view(n, Ho, Wo, 64)
+                # the stem's 49 taps of ONE input channel are no multiple of 64 channels: its im2col rows (padded to 64, rounded on the way out)
+                # are the "pixels" of a 1 x 1 convolution; everything behind it, the max pool included, is 16-bit
+                col = hip.im2col_nhwc(x, 7, 7, 2, 3, kpad, out_dtype=p["dtype"]).view(n, Ho, Wo, kpad)
+                y = hip.conv_gemm16(col, w, b, 1, 1, 1, 0, epilogue=hip.EPI_BIAS_RELU).view(n, Ho, Wo, 64)
                 del col
                 y = hip.maxpool_nhwc(y)
-                y = hip.cvt16(y.view(-1, 64), p["dtype"]).view(y.shape)
             for e in p["blocks"]:
                 n, H, W, Cin = y.shape
                 s = e["stride"]

