@@ -288,3 +288,44 @@ def test_block_stream_packer_and_layout_helpers_cpu():
     assert float(blk[1, 5, 7 + 32, 3]) == float(a[32 + 7, 16 * 5 + 8 + 3])          # row 7 of group 1, column 16*5 + 8*1 + 3
     img = hip.to_image32(a).view(3, 48, 64, 4)
     assert float(img[2, 9, 11 + 32, 1]) == float(a[64 + 11, 8 * 9 + 4 + 1])
+
+
+def test_convolution_gradient_operand_layouts_cpu():
+    """Host-side layouts of the implicit-GEMM gradients, checked with torch on the CPU (the kernels themselves: tests/test_resnet_gpu.py):
+    mst_conv_dgrad computes a stride-1 convolution of the stride-dilated gradient, padded by k - 1 - pad, with the weight
+    hip.conv_dgrad_weight builds ([Cin, (ky', kx', co)], both kernel axes flipped) -- that must be autograd's input gradient."""
+    import torch.nn.functional as F
+    from mst import hip
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, k, stride, pad, hw in ((4, 6, 3, 1, 1, (7, 6)), (4, 6, 3, 2, 1, (9, 8)), (3, 5, 1, 2, 0, (7, 5)), (2, 3, 3, 2, 1, (6, 6))):
+        x = torch.randn(2, cin, *hw, generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64)
+        y = F.conv2d(x, w, stride=stride, padding=pad)
+        dz = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        y.backward(dz)
+        Ho, Wo = y.shape[2:]
+        dil = torch.zeros(2, cout, (Ho - 1) * stride + 1, (Wo - 1) * stride + 1, dtype=torch.float64)
+        dil[:, :, ::stride, ::stride] = dz                                        # the gradient rows on every stride-th position
+        pt = k - 1 - pad
+        # pad so that the stride-1 convolution has exactly H x W outputs (the kernel bounds-checks instead of padding)
+        dil = F.pad(dil, (pt, hw[1] + k - 1 - pt - dil.shape[3], pt, hw[0] + k - 1 - pt - dil.shape[2]))
+        wt = hip.conv_dgrad_weight(w, torch.float64)                              # [Cin, (ky', kx', co)]
+        dx = F.conv2d(dil, wt.view(cin, k, k, cout).permute(0, 3, 1, 2))
+        assert dx.shape == x.shape and torch.allclose(dx, x.grad, atol=1e-12)
+
+
+def test_build_specific_precision_keywords_are_validated_cpu():
+    import warnings
+    from mst.models import DinoV2ClassifierSlice, ResNetSliceTrans
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, compute_dtype="bf16", train_precision="fp16")
+        assert (m.compute_dtype_name, m.train_precision) == ("bf16", "fp16")
+        assert ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False).compute_dtype_name == "fp32"
+        for kw in (dict(compute_dtype="fp8"), dict(train_precision="int8")):
+            with pytest.raises(ValueError):
+                ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, **kw)
+    d = DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, train_precision="bf16")
+    assert d.train_precision == "bf16" and DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False).train_precision == "fp32"
+    with pytest.raises(ValueError):
+        DinoV2ClassifierSlice(in_ch=1, out_ch=2, pretrained=False, train_precision="fp8")
