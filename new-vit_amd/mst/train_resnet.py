@@ -51,16 +51,25 @@ def _conv_bn_fwd(x: torch.Tensor, conv, bn, k: int, stride: int, pad: int, sum_i
     n, H, W, Cin = x.shape
     wg = _gemm_weight(conv, sum_in)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    mp = mp if (mp is not None and Cin % 64 == 0 and wg.shape[0] % 64 == 0) else None
-    if mp is not None:
-        z = hip.conv_gemm16(hip.cvt16(x.view(-1, Cin), mp).view(x.shape), hip.cvt16(wg, mp), None, k, k, stride, pad, epilogue=hip.EPI_BIAS,
-                            out_dtype=torch.float32)
+    Cout = wg.shape[0]
+    x16 = col16 = None
+    if mp is not None and Cin % 64 == 0 and Cout % 64 == 0:
+        x16 = hip.cvt16(x.view(-1, Cin), mp).view(x.shape)               # kept for the weight gradient (a third of the step's conversions otherwise)
+        z = hip.conv_gemm16(x16, hip.cvt16(wg, mp), None, k, k, stride, pad, epilogue=hip.EPI_BIAS, out_dtype=torch.float32)
+    elif mp is not None and Cout % 64 == 0 and k * k * Cin <= 64:
+        # the stem (one input channel after the gray fold: 49 taps): its im2col rows, rounded on the way out and padded to 64 columns, are the
+        # "pixels" of a 1 x 1 convolution -- for the forward and for the weight gradient (no fp32 im2col matrix, no strided fp32 GEMM)
+        w64 = torch.zeros((Cout, 64), dtype=torch.float32, device=x.device)
+        w64[:, :k * k * Cin] = wg[:, :k * k * Cin]
+        col16 = hip.im2col_nhwc(x, k, k, stride, pad, 64, out_dtype=mp).view(n * Ho * Wo, 1, 1, 64)
+        z = hip.conv_gemm16(col16, hip.cvt16(w64, mp), None, 1, 1, 1, 0, epilogue=hip.EPI_BIAS, out_dtype=torch.float32)
     else:
+        mp = None
         z = _conv(x, wg, None, k, stride, pad, wg.shape[1], hip.EPI_BIAS)    # implicit GEMM behind the stem
     y, mean, rstd = hip.batchnorm_train(z, bn, residual, relu)
     bn.num_batches_tracked += 1
     rec = {"x": x, "z": z, "y": y if relu else None, "mean": mean, "rstd": rstd, "wg": wg, "k": k, "stride": stride, "pad": pad,
-           "sum_in": sum_in, "relu": relu, "conv": conv, "bn": bn, "mp": mp}
+           "sum_in": sum_in, "relu": relu, "conv": conv, "bn": bn, "mp": mp, "x16": x16, "col16": col16}
     return y.view(n, Ho, Wo, wg.shape[0]), rec
 
 
@@ -91,8 +100,11 @@ def _conv_bn_bwd(G: _Grads, rec, dy: torch.Tensor, need_dx: bool) -> Optional[to
     col = None
     mp = rec["mp"]
     dz16 = hip.cvt16(dz, mp) if mp is not None else None                # shared by the two gradients
-    if implicit and mp is not None and Cin % 64 == 0 and Cout % 64 == 0:
-        dwg = hip.conv_wgrad(dz16, hip.cvt16(x.view(-1, Cin), mp).view(x.shape), k, stride, pad)     # 16-bit operands, fp32 partial products
+    if mp is not None and rec["col16"] is not None:                      # the stem under mixed precision: d weight over its 16-bit im2col "pixels"
+        dwg = torch.zeros((Cout, kpad), dtype=torch.float32, device=dev)
+        dwg[:, :min(kpad, 64)] = hip.conv_wgrad(dz16, rec["col16"], 1, 1, 0)[:, :min(kpad, 64)]
+    elif implicit and mp is not None and rec["x16"] is not None:
+        dwg = hip.conv_wgrad(dz16, rec["x16"], k, stride, pad)           # 16-bit operands (the forward's image of x), fp32 partial products
     elif implicit and Cin % 64 == 0 and Cout % 4 == 0:
         dwg = hip.conv_wgrad(dz, x, k, stride, pad)                      # implicit GEMM: no im2col matrix
     else:
