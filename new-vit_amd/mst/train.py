@@ -34,10 +34,13 @@ def _mp(model) -> Optional[torch.dtype]:
     return _MP[getattr(model, "train_precision", "fp32")]
 
 
-def _lin_fwd(x: torch.Tensor, lin, mp: Optional[torch.dtype] = None, **kw) -> torch.Tensor:
+def _lin_fwd(x: torch.Tensor, lin, mp: Optional[torch.dtype] = None, keep: Optional[dict] = None, **kw) -> torch.Tensor:
     if mp is None:
         return hip.gemm(x, lin.weight.detach(), lin.bias.detach(), **kw)
-    return hip.gemm(hip.cvt16(x, mp), hip.cvt16(lin.weight.detach(), mp), lin.bias.detach(), out_dtype=torch.float32, **kw)
+    x16 = hip.cvt16(x, mp)
+    if keep is not None and x.shape[0] <= 12288:         # the weight gradient of this product reads the same image (mst_conv_wgrad16 path)
+        keep[id(lin)] = x16
+    return hip.gemm(x16, hip.cvt16(lin.weight.detach(), mp), lin.bias.detach(), out_dtype=torch.float32, **kw)
 
 
 class _Grads:
@@ -52,13 +55,13 @@ class _Grads:
         else:
             self.by_param[id(param)] = g
 
-    def lin_bwd(self, dY: torch.Tensor, X: torch.Tensor, lin, need_dx: bool = True) -> Optional[torch.Tensor]:
+    def lin_bwd(self, dY: torch.Tensor, X: torch.Tensor, lin, need_dx: bool = True, X16: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """nn.Linear backward: d weight = dY^T . X, d bias = column sums of dY, returns dX = dY . W."""
         M, N = dY.shape
         K = X.shape[1]
         dev = dY.device
         if self.mp is not None and N % 128 == 0 and K % 128 == 0 and M >= 64:
-            return self._lin_bwd_16(dY, X, lin, need_dx)
+            return self._lin_bwd_16(dY, X, lin, need_dx, X16)
         # d weight: an [N, K] output reduced over M rows is 36-144 tiles walking thousands of rows each; split the rows into up to
         # 16 slabs (more workgroups than CUs), partial products reduced by mst_colsum
         sp = next((d for d in (16, 8, 4, 2) if M % d == 0 and M // d >= 64), 1)
@@ -79,7 +82,7 @@ class _Grads:
         hip.gemm_ex(dY, lin.weight.detach(), dX, M, K, N, sa=(N, 1), sb=(K, 1), sc=(K, 1))
         return dX
 
-    def _lin_bwd_16(self, dY: torch.Tensor, X: torch.Tensor, lin, need_dx: bool) -> Optional[torch.Tensor]:
+    def _lin_bwd_16(self, dY: torch.Tensor, X: torch.Tensor, lin, need_dx: bool, X16: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """The same three results on 16-bit MFMA operands (fp32 accumulation, fp32 results): operands are rounded into scratch images right
         before each product."""
         M, N = dY.shape
@@ -91,7 +94,8 @@ class _Grads:
             # d weight = dY^T . X is the weight gradient of a 1 x 1 "convolution" over M one-pixel images: mst_conv_wgrad16 reads both operands
             # row-major (token-major) and transposes the fragments in the LDS read -- no transposed operand images, token-split partial
             # products (1 x 16 x 224^2: 14.4 -> 10.9 ms per step against the form below)
-            self.put(lin.weight, hip.conv_wgrad(dY16, hip.cvt16(X, mp).view(M, 1, 1, K), 1, 1, 0))
+            x16 = X16 if (X16 is not None and X16.dtype == mp and X16.shape == X.shape) else hip.cvt16(X, mp)   # the forward's image, if it was kept
+            self.put(lin.weight, hip.conv_wgrad(dY16, x16.view(M, 1, 1, K), 1, 1, 0))
         else:
             # many tokens: TRANSPOSED operand images (both operands contiguous along the token index) through the 128 x 128 x 64 GEMM with
             # 16-byte fragment reads, split over the tokens (mst_gemm16_splitk): 3 % faster at 16,448 tokens than the transposing reads
@@ -269,18 +273,19 @@ def forward_train(model, source: torch.Tensor, mask: Optional[torch.Tensor], wit
     blocks = []
     mp = _mp(model)
     for blk in enc.block_list():
-        s = {"x0": xt}
+        s = {"x0": xt, "x16": {}}
+        k16 = s["x16"] if mp is not None else None
         s["xn1"] = hip.layernorm(xt, blk.norm1.weight.detach(), blk.norm1.bias.detach(), 1e-6)
-        s["qkv"] = _lin_fwd(s["xn1"], blk.attn.qkv, mp, col_scale=0.125, scale_cols=E)            # q * head_dim^-0.5 (attention.py:60)
+        s["qkv"] = _lin_fwd(s["xn1"], blk.attn.qkv, mp, k16, col_scale=0.125, scale_cols=E)            # q * head_dim^-0.5 (attention.py:60)
         s["a"], s["P"] = _attention_fwd(s["qkv"], n, N, heads, 64, 1.0, None)
-        s["br1"] = _lin_fwd(s["a"], blk.attn.proj, mp)
+        s["br1"] = _lin_fwd(s["a"], blk.attn.proj, mp, k16)
         x1 = xt.clone()
         hip.axpby_cols(s["br1"], x1, g=blk.ls1.gamma.detach() if hasattr(blk, "ls1") else None)
         s["x1"] = x1
         s["xn2"] = hip.layernorm(x1, blk.norm2.weight.detach(), blk.norm2.bias.detach(), 1e-6)
-        s["hpre"] = _lin_fwd(s["xn2"], blk.mlp.fc1, mp)
+        s["hpre"] = _lin_fwd(s["xn2"], blk.mlp.fc1, mp, k16)
         s["hact"] = hip.act_fwd(s["hpre"], 0)
-        s["br2"] = _lin_fwd(s["hact"], blk.mlp.fc2, mp)
+        s["br2"] = _lin_fwd(s["hact"], blk.mlp.fc2, mp, k16)
         x2 = x1.clone()
         hip.axpby_cols(s["br2"], x2, g=blk.ls2.gamma.detach() if hasattr(blk, "ls2") else None)
         blocks.append(s)
@@ -359,9 +364,10 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
             G.put(blk.ls2.gamma, hip.colsum(dx, torch.zeros(E, dtype=torch.float32, device=dev), b=s["br2"]))
             dbr = torch.empty_like(dx)
             hip.axpby_cols(dx, dbr, g=blk.ls2.gamma.detach(), beta=0.0)
-        dh = G.lin_bwd(dbr, s["hact"], blk.mlp.fc2)
+        x16 = s.get("x16", {})
+        dh = G.lin_bwd(dbr, s["hact"], blk.mlp.fc2, X16=x16.get(id(blk.mlp.fc2)))
         hip.act_bwd(s["hpre"], dh, 0)
-        dxn2 = G.lin_bwd(dh, s["xn2"], blk.mlp.fc1)
+        dxn2 = G.lin_bwd(dh, s["xn2"], blk.mlp.fc1, X16=x16.get(id(blk.mlp.fc1)))
         dx1 = torch.empty_like(dx)
         G.ln_bwd(s["x1"], E, blk.norm2, dxn2, E, dx, E, dx1, E, M, E, 1e-6)
         # x1 = x0 + ls1 * proj(attn(qkv(norm1 x0)))
@@ -370,9 +376,9 @@ def backward_train(model, sv, dout: torch.Tensor) -> Dict[int, torch.Tensor]:
             G.put(blk.ls1.gamma, hip.colsum(dx1, torch.zeros(E, dtype=torch.float32, device=dev), b=s["br1"]))
             dbr = torch.empty_like(dx1)
             hip.axpby_cols(dx1, dbr, g=blk.ls1.gamma.detach(), beta=0.0)
-        da = G.lin_bwd(dbr, s["a"], blk.attn.proj)
+        da = G.lin_bwd(dbr, s["a"], blk.attn.proj, X16=x16.get(id(blk.attn.proj)))
         dqkv = _attention_bwd(da, s["qkv"], s["P"], n, N, heads, 64, 1.0, 0.125)
-        dxn1 = G.lin_bwd(dqkv, s["xn1"], blk.attn.qkv)
+        dxn1 = G.lin_bwd(dqkv, s["xn1"], blk.attn.qkv, X16=x16.get(id(blk.attn.qkv)))
         dx0 = torch.empty_like(dx)
         G.ln_bwd(s["x0"], E, blk.norm1, dxn1, E, dx1, E, dx0, E, M, E, 1e-6)
         dx = dx0
