@@ -620,6 +620,15 @@ def test_mixed_precision_convolution_unit_and_training_steps(prec):
         losses[p] = hist
     assert abs(losses[prec][0] - losses["fp32"][0]) < 0.1 * losses["fp32"][0], losses
     assert losses[prec][-1] < losses[prec][0], losses
+    # bottleneck units (1 x 1 -> 3 x 3 -> 1 x 1, 2048-wide embeddings) take the same three 16-bit products
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, model=50, train_precision=prec)
+    m.load_state_dict(synth.synth_resnet_state_dict(7, 50, 2), strict=True)
+    m = m.cuda().train()
+    loss = torch.nn.functional.cross_entropy(m(src[:, :, :2]), tgt)
+    loss.backward()
+    assert torch.isfinite(loss) and all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters())
     with pytest.raises(ValueError):
         ResNetSliceTrans(in_ch=1, out_ch=2, pretrained=False, train_precision="fp8")
 
