@@ -6,16 +6,20 @@ forward runs the model op by op through the C ABI and whose backward produces ev
 
   convolution      z = im2col(x) . Wg^T             (mst_conv_gemm: implicit GEMM, exact fp32 MFMA; the stem: mst_im2col_nhwc + mst_gemm;
                                                      Wg = weight in (ky, kx, c) order)
-     backward      dWg = dz^T . im2col(x) (split over images, partial sums reduced by mst_colsum), dx = col2im(dz . Wg)
+     backward      dWg = dz^T . im2col(x) as an implicit GEMM too (mst_conv_wgrad: pixel-split partial products reduced by mst_colsum),
+                   dx = the stride-1 convolution of the stride-dilated dz with the flipped, transposed weight (mst_conv_dgrad); the
+                   stem and MST_CONV_IM2COL=1 keep the explicit forms (mst_im2col_nhwc + mst_gemm_ex, mst_col2im_nhwc)
+     16-bit        train_precision = bf16 / fp16 (the reference's Trainer(precision='16-mixed')): the three products on 16-bit MFMA
+                   operands with fp32 accumulation (mst_conv_gemm16, mst_conv_dgrad, mst_conv_wgrad16); everything else and all
+                   stored tensors fp32
   BatchNorm2d      batch statistics + running-stat update (mst_batchnorm_train), residual add and ReLU in the same pass
      backward      mst_batchnorm_bwd (ReLU mask first: mst_act_bwd on the saved output)
   max / avg pool   mst_maxpool_bwd_nhwc / mst_avgpool_bwd_nhwc
   slice fusion     mst.train.fusion_fwd / fusion_bwd with 16 heads over 512-wide tokens
 
 BatchNorm in train mode normalises over ALL (B D) images of the step, so the step is not chunked: activations of the whole batch stay
-resident (fp32 NHWC; about 60 MB per 224^2 image for resnet34 -- sized for 288 GB of HBM).  The im2col matrix is rebuilt in the
-backward instead of being kept.  Checked against torch.autograd of oracle/resnet_oracle.py on every parameter
-(tests/test_resnet_gpu.py).
+resident (fp32 NHWC; about 60 MB per 224^2 image for resnet34 -- sized for 288 GB of HBM; the mixed mode keeps a 16-bit image of every
+convolution input beside it).  Checked against torch.autograd of oracle/resnet_oracle.py on every parameter (tests/test_resnet_gpu.py).
 """
 from __future__ import annotations
 
