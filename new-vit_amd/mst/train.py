@@ -7,10 +7,12 @@ backward produces the gradient of every parameter with the kernels of csrc/k_tra
 `mst_softmax_rows_bwd`, `mst_act_bwd`, ...).  The loss itself stays the reference's own ``torch.nn.CrossEntropyLoss`` call on the
 [B, out_ch] logits (host code).  torch is used for memory only (allocation, views, concatenation / copies of whole tensors).
 
-First correct version: everything in exact fp32 (fp32 MFMA), whatever ``compute_dtype`` the inference path uses; the attention
-probabilities of every block are kept ([n, heads, N, N] fp32: 2.9 GB per block at 64 x 518^2 -- sized for 288 GB of HBM).
-Checked against autograd of the CPU oracle on every parameter (tests/test_train_gpu.py).  Not supported yet (raise): rotary
-variants of the slice transformer, register tokens, ``save_attn`` inside a training forward.
+Default: everything in exact fp32 (fp32 MFMA), whatever ``compute_dtype`` the inference path uses -- the mode the gradient parity bar
+(1e-3 against autograd of the CPU oracle on every parameter, tests/test_train_gpu.py) is on.  ``train_precision='fp16' | 'bf16'`` (the
+reference's Trainer(precision='16-mixed'), scripts/main_train.py:110-123) runs the blocks' nn.Linear products -- forward, d input, d weight
+-- on 16-bit MFMA operands with fp32 accumulation; every other op and everything stored stays fp32.  The attention probabilities of every
+block are kept ([n, heads, N, N] fp32: 2.9 GB per block at 64 x 518^2 -- sized for 288 GB of HBM).  RoPE slice transformers and
+register-token encoders (at their stored position grid) train; raise: the LieRE variant, ``save_attn`` inside a training forward.
 """
 from __future__ import annotations
 
